@@ -1,0 +1,185 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X (gfx950) sphere path tracer.
+ *
+ * This library replaces the traced path of the reference renderer: the class
+ * RayTracer (src/rt/RayTracer.h:34-94), its Vulkan dispatch
+ * (src/rt/RayTracer.cpp:559-685) and the compute shader it launches
+ * (shaders/raytrace.comp.glsl).  Every entry point below names the reference
+ * interface it stands in for.  All functions return 0 on success or a
+ * non-zero rt_status; nothing throws across this boundary.  A handle is used
+ * from one thread at a time; one handle drives one GPU.
+ *
+ * Images are linear row-major, row 0 = top, pitch = width: the accumulator is
+ * float4 per pixel (the rgba32f storage image, binding 0), the output is
+ * uchar4 per pixel (the rgba8 swapchain image, binding 1).
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GPUSphere, src/rt/RayTracer.h:12-17 == struct Sphere, raytrace.comp.glsl:7-12
+ * (std430, stride 48). */
+typedef struct rt_gpu_sphere {
+    float center_radius[4]; /* xyz centre, w radius */
+    float albedo[4];        /* rgb albedo, w unused */
+    float misc[4];          /* x material (0 lambert, 1 metal, 2 dielectric), y fuzz, z refIdx, w flags (>0.5: checker) */
+} rt_gpu_sphere;
+
+/* GPUParams, src/rt/RayTracer.h:20-32 == uniform Params, raytrace.comp.glsl:19-31
+ * (std140, 160 bytes). */
+typedef struct rt_gpu_params {
+    float origin_lens[4];   /* xyz origin, w lens radius */
+    float lower_left[4];
+    float horizontal[4];
+    float vertical[4];
+    float u[4];
+    float v[4];
+    float w[4];
+    uint32_t frame_sample_depth_count[4]; /* frame, samples per frame, max depth, sphere count */
+    float resolution[4];    /* x width, y height */
+    float inv_resolution[4];
+} rt_gpu_params;
+
+typedef struct rt_tracer *rt_handle;
+
+/* device_id for rt_create that builds a handle holding host state only (no HIP
+ * call is made): setters, rt_get_params, rt_get_spheres and rt_resize work,
+ * every call that needs the GPU returns RT_ERR_NO_DEVICE. */
+#define RT_DEVICE_NONE (-1)
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_BAD_ARGUMENT = 1,
+    RT_ERR_HIP = 2,          /* a HIP runtime call failed; see rt_last_error */
+    RT_ERR_NO_DEVICE = 3,
+    RT_ERR_OUT_OF_MEMORY = 4
+} rt_status;
+
+/* RayTracer::create, src/rt/RayTracer.cpp:179-199.  Allocates the accumulator
+ * and output images for width x height on HIP device device_id, installs the
+ * default five-sphere scene (:105-138), aims the default camera (13,2,3) at
+ * (0,1,0) with focus = distance (:189-193) and raises the reset flag.  Member
+ * defaults are those of RayTracer.h:87-93 (spp 4, depth 12, aperture 0.05,
+ * vfov 20). */
+int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle *out);
+
+/* RayTracer::resize, src/rt/RayTracer.cpp:201-234: waits for the device,
+ * re-allocates the images at the new extent, raises the reset flag. */
+int rt_resize(rt_handle h, uint32_t width, uint32_t height);
+
+/* RayTracer::destroy, src/rt/RayTracer.cpp:236-296. */
+int rt_destroy(rt_handle h);
+
+/* RayTracer::setCamera, src/rt/RayTracer.cpp:298-309: stores pos and
+ * normalize(dir); focus_dist is taken only when > 0; raises the reset flag. */
+int rt_set_camera(rt_handle h, const float pos[3], const float dir[3], float focus_dist);
+/* RayTracer::setSamplesPerPixel, :311-315 (max(1, spp)). */
+int rt_set_samples_per_pixel(rt_handle h, uint32_t spp);
+/* RayTracer::setAperture, :317-321 (max(0, aperture)). */
+int rt_set_aperture(rt_handle h, float aperture);
+/* RayTracer::setFocusDistance, :323-330 (ignored, flag untouched, unless > 0). */
+int rt_set_focus_distance(rt_handle h, float focus_dist);
+/* RayTracer::setFov, :332-336 (clamped to [5, 120] degrees). */
+int rt_set_fov(rt_handle h, float vfov_deg);
+/* RayTracer::setMaxDepth, :338-342 (max(1, depth)). */
+int rt_set_max_depth(rt_handle h, uint32_t depth);
+
+/* Replaces the sphere list that RayTracer::buildScene/uploadScene
+ * (src/rt/RayTracer.cpp:105-138, :529-548) hard-code.  The reference has no
+ * public counterpart; this is what larger scenes enter through.  n >= 1.
+ * Raises the reset flag. */
+int rt_set_spheres(rt_handle h, const rt_gpu_sphere *spheres, uint32_t n);
+/* Copies out up to cap spheres of the current scene; *n receives the count. */
+int rt_get_spheres(rt_handle h, rt_gpu_sphere *out, uint32_t cap, uint32_t *n);
+
+/* RayTracer::makeCameraParams + updateParams, src/rt/RayTracer.cpp:140-177,
+ * :550-557: the 160-byte block a dispatch for frame_index would receive. */
+int rt_get_params(rt_handle h, uint32_t frame_index, rt_gpu_params *out);
+
+/* Raises the reset flag without changing any setting (what every setter and
+ * create/resize do as a side effect, RayTracer.h:81). */
+int rt_reset_accumulation(rt_handle h);
+
+/* RayTracer::render, src/rt/RayTracer.cpp:559-685: clears the accumulator iff
+ * the reset flag is up or frame_index == 0 (:564), lowers the flag, then runs
+ * one dispatch of the shader for frame_index (raytrace.comp.glsl:298-343) over
+ * the whole image.  Asynchronous on `stream` (a hipStream_t; NULL = the
+ * device's default stream), like the reference's recording into the caller's
+ * command buffer.  Successive calls on one stream are ordered. */
+int rt_render(rt_handle h, uint32_t frame_index, void *stream);
+
+/* n_frames consecutive rt_render calls (frame_index = first_frame ..
+ * first_frame + n_frames - 1) as one launch: same accumulator bits, the output
+ * image is that of the last frame.  This is the caller loop of
+ * src/core/App.cpp:403,527 folded into the device. */
+int rt_render_frames(rt_handle h, uint32_t first_frame, uint32_t n_frames, void *stream);
+
+/* The sharded form of rt_render_frames used across GPUs: renders frames
+ * first_frame, first_frame + frame_stride, ... (n_frames of them) for rows
+ * [row_begin, row_end) only.  Pixel coordinates stay global, so every texel
+ * gets the same RNG stream as on one GPU (raytrace.comp.glsl:310-311).  The
+ * clear rule is that of rt_render applied to first_frame.  With
+ * write_output == 0 the rgba8 image is left untouched (a frame-split rank
+ * resolves it after the reduction with rt_resolve_output). */
+int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                    uint32_t row_begin, uint32_t row_end, int write_output, void *stream);
+
+/* The display tail of the shader alone, raytrace.comp.glsl:337-342: divides the
+ * accumulator by float(sample_count), applies c/(c+1) and pow(max(c,0),1/2.2),
+ * stores rgba8 for rows [row_begin,row_end).  sample_count is the shader's
+ * (frame + 1) * spp. */
+int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *stream);
+
+/* Device addresses of the two images (bindings 0 and 1 of
+ * raytrace.comp.glsl:33-34).  Valid until rt_resize/rt_destroy. */
+void *rt_accum_device_ptr(rt_handle h);
+void *rt_output_device_ptr(rt_handle h);
+
+/* Blocking copies (they synchronise `stream` first).  bytes must equal
+ * width*height*16 (accum) or width*height*4 (output). */
+int rt_read_accum(rt_handle h, float *host, size_t bytes, void *stream);
+int rt_write_accum(rt_handle h, const float *host, size_t bytes, void *stream);
+int rt_read_output(rt_handle h, uint8_t *host, size_t bytes, void *stream);
+
+/* Test hook: when enabled, every dispatch also stores the RNG state each pixel
+ * ends with (after its last sample of the last frame) so that the per-pixel
+ * stream of raytrace.comp.glsl:310-331 can be compared word for word. */
+int rt_enable_rng_capture(rt_handle h, int enable);
+int rt_read_rng_state(rt_handle h, uint32_t *host, size_t bytes, void *stream);
+
+/* Waits for `stream` (vkDeviceWaitIdle in the reference's resize/destroy). */
+int rt_synchronize(rt_handle h, void *stream);
+
+int rt_get_extent(rt_handle h, uint32_t *width, uint32_t *height);
+
+/* Milliseconds the most recent trace kernel of this handle took on the GPU,
+ * measured with HIP events on the stream it was launched on; blocks until that
+ * kernel has finished.  Negative if nothing has been launched. */
+float rt_last_kernel_ms(rt_handle h);
+
+/* Text of the last error on this handle (VK_CHECK's message in the reference,
+ * src/util/Check.h:8-19).  h may be NULL: then the last rt_create failure. */
+const char *rt_last_error(rt_handle h);
+
+/* Device-side probes of single shader functions, for vector tests: evaluate
+ * the function for n inputs on the GPU with the same code the tracer uses. */
+/* hitSphere, raytrace.comp.glsl:109-153.  rays: n x 8 floats (o.xyz, tmin, d.xyz, tmax);
+ * spheres: n spheres; out: n x 8 floats (hit flag, t, p.xyz, n.xyz) ; front: n ints. */
+int rt_probe_hit_sphere(int device_id, const rt_gpu_sphere *spheres, const float *rays, uint32_t n,
+                        float *out, int32_t *front);
+/* pow as the tracer evaluates it (schlick :196, tonemap :340). */
+int rt_probe_pow(int device_id, const float *x, const float *y, uint32_t n, float *out);
+/* hash/lcg/rand, raytrace.comp.glsl:37-55: for each of n seeds (x,y,z) returns the
+ * hash and the first `draws` lcg states. out: n x (1 + draws) words. */
+int rt_probe_rng(int device_id, const uint32_t *xyz, uint32_t n, uint32_t draws, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

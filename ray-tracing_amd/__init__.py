@@ -1,0 +1,11 @@
+"""MI355X-native sphere path tracer: the traced path of RippleDomain/Ray-Tracing behind a C ABI.
+
+The directory name carries a hyphen, so import it through rtamd_loader.load()
+(repo root), which registers it as the module `raytracing_amd`.
+"""
+from .tracer import (ABI, GPUParams, GPUSphere, LIB_PATH, RayTracer, load_library, probe_hit_sphere, probe_pow,
+                     probe_rng)
+from .scene import default_scene, synthetic_scene
+
+__all__ = ["ABI", "GPUParams", "GPUSphere", "LIB_PATH", "RayTracer", "load_library", "probe_hit_sphere",
+           "probe_pow", "probe_rng", "default_scene", "synthetic_scene"]

@@ -1,0 +1,244 @@
+// Device-side arithmetic of the sphere path tracer (gfx950).
+//
+// Every function here is the HIP counterpart of one function of the reference
+// compute shader shaders/raytrace.comp.glsl; the line ranges are given at each
+// definition.  The translation unit that includes this header MUST be compiled
+// with -ffp-contract=off and without fast-math: the per-pixel random streams
+// are steered by float comparisons, so every +,-,*,/ and sqrt below has to be
+// one correctly rounded IEEE-754 binary32 operation, in shader source order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+struct f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+// GLSL dot(): products summed left to right.
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// GLSL min/max: "y if y < x, otherwise x" / "y if x < y, otherwise x".
+__device__ __forceinline__ float glsl_min(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float glsl_max(float x, float y) { return (x < y) ? y : x; }
+// inversesqrt as two correctly rounded steps; normalize(v) = v * inversesqrt(dot(v,v)).
+__device__ __forceinline__ float inversesqrt(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ f3 normalize(f3 a) { return a * inversesqrt(dot(a, a)); }
+// reflect(I, N) = I - 2.0 * dot(N, I) * N
+__device__ __forceinline__ f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
+
+// ---------------------------------------------------------------- RNG
+// raytrace.comp.glsl:37-44 (one component of the uvec3 hash)
+__device__ __forceinline__ uint32_t hash1(uint32_t v)
+{
+    v = (v ^ (v >> 17)) * 0xED5AD4BBu;
+    v = (v ^ (v >> 11)) * 0xAC4C1B51u;
+    v = (v ^ (v >> 15)) * 0x31848BABu;
+    return v;
+}
+__device__ __forceinline__ uint32_t hash3(uint32_t x, uint32_t y, uint32_t z)
+{
+    return hash1(x) ^ hash1(y) ^ hash1(z);
+}
+// raytrace.comp.glsl:46-50
+__device__ __forceinline__ uint32_t lcg(uint32_t& state)
+{
+    state = 1664525u * state + 1013904223u;
+    return state;
+}
+// raytrace.comp.glsl:52-55.  The divide by 2^24 is exact, so a multiply by
+// 2^-24 produces the same bits.
+__device__ __forceinline__ float rnd(uint32_t& state)
+{
+    return (float)(lcg(state) & 0x00FFFFFFu) * 5.9604644775390625e-08f;
+}
+
+// ---------------------------------------------------------------- pow
+// GLSL pow(x,y) inherits its precision from exp2(y*log2(x)).  These kernels use
+// only +,-,*,/ and integer bit operations in a fixed order, so the host-side
+// checker reproduces them bit for bit (schlick :196 feeds a comparison that
+// steers the random stream).
+__device__ __forceinline__ float portable_log2(float x)
+{
+    uint32_t ix = __float_as_uint(x);
+    int k = 0;
+    if (ix >= 0x7f800000u) {
+        return (ix > 0x80000000u && ix <= 0xff800000u) ? __uint_as_float(0x7fc00000u) : x;
+    }
+    if (ix == 0u) {
+        return __uint_as_float(0xff800000u);
+    }
+    if (ix < 0x00800000u) {
+        x = x * 8388608.0f;
+        k = -23;
+        ix = __float_as_uint(x);
+    }
+    k += (int)(ix >> 23) - 127;
+    ix &= 0x007fffffu;
+    uint32_t i = (ix + 0x004afb20u) & 0x00800000u;
+    float m = __uint_as_float(ix | (i ^ 0x3f800000u));
+    k += (int)(i >> 23);
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    float R = t2 + t1;
+    float hfsq = (0.5f * f) * f;
+    float lnm = f - (hfsq - s * (hfsq + R));
+    return (float)k + lnm * 1.44269504089f;
+}
+
+__device__ __forceinline__ float pow2i(int n) { return __uint_as_float((uint32_t)(n + 127) << 23); }
+
+__device__ __forceinline__ float portable_exp2(float p)
+{
+    if (!(p == p)) {
+        return p;
+    }
+    if (p >= 128.0f) {
+        return __uint_as_float(0x7f800000u);
+    }
+    if (p < -150.0f) {
+        return 0.0f;
+    }
+    float n = floorf(p + 0.5f);
+    float r = p - n;
+    float q = 1.52527338041e-5f;
+    q = 1.54035303934e-4f + r * q;
+    q = 1.33335581464e-3f + r * q;
+    q = 9.61812910763e-3f + r * q;
+    q = 5.55041086648e-2f + r * q;
+    q = 2.40226506959e-1f + r * q;
+    q = 6.93147180560e-1f + r * q;
+    q = 1.0f + r * q;
+    int ni = (int)n;
+    if (ni > 127) {
+        return (q * pow2i(127)) * pow2i(ni - 127);
+    }
+    if (ni < -126) {
+        return (q * pow2i(ni + 24)) * pow2i(-24);
+    }
+    return q * pow2i(ni);
+}
+
+__device__ __forceinline__ float glsl_pow(float x, float y)
+{
+    if (x == 0.0f) {
+        return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : __uint_as_float(0x7f800000u));
+    }
+    return portable_exp2(y * portable_log2(x));
+}
+
+// ---------------------------------------------------------------- samplers
+// raytrace.comp.glsl:57-68
+__device__ __forceinline__ f3 random_in_unit_sphere(uint32_t& rng)
+{
+    f3 p;
+    do {
+        float a = rnd(rng);
+        float b = rnd(rng);
+        float c = rnd(rng);
+        p = mk(a * 2.0f - 1.0f, b * 2.0f - 1.0f, c * 2.0f - 1.0f);
+    } while (dot(p, p) >= 1.0f);
+    return p;
+}
+
+// raytrace.comp.glsl:75-86 (z is always 0)
+__device__ __forceinline__ void random_in_unit_disk(uint32_t& rng, float& dx, float& dy)
+{
+    do {
+        float a = rnd(rng);
+        float b = rnd(rng);
+        dx = a * 2.0f - 1.0f;
+        dy = b * 2.0f - 1.0f;
+    } while ((dx * dx + dy * dy) >= 1.0f);
+}
+
+// ---------------------------------------------------------------- intersection
+// The root-finding half of hitSphere, raytrace.comp.glsl:111-133.  geom = (centre, radius^2);
+// a = dot(d,d) is the same for every sphere of one ray and is passed in.
+// Returns true and the accepted root when the sphere is hit inside [tmin, tmax].
+__device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, float a, float tmin, float tmax, float& root_out)
+{
+    f3 oc = o - mk(geom.x, geom.y, geom.z);
+    float half_b = dot(oc, d);
+    float c = dot(oc, oc) - geom.w;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) {
+        return false;
+    }
+    float sqrt_disc = sqrtf(discriminant);
+    float root = (-half_b - sqrt_disc) / a;
+    if (root < tmin || root > tmax) {
+        root = (-half_b + sqrt_disc) / a;
+        if (root < tmin || root > tmax) {
+            return false;
+        }
+    }
+    root_out = root;
+    return true;
+}
+
+// The record-filling half of hitSphere, raytrace.comp.glsl:135-143.
+__device__ __forceinline__ void hit_finish(f3 centre, float radius, f3 o, f3 d, float t, f3& p, f3& n, bool& front)
+{
+    p = o + d * t;
+    n = (p - centre) / radius;
+    front = dot(d, n) < 0.0f;
+    if (!front) {
+        n = -n;
+    }
+}
+
+// schlick, raytrace.comp.glsl:192-197
+__device__ __forceinline__ float schlick(float cosine, float ref_idx)
+{
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 *= r0;
+    return r0 + (1.0f - r0) * glsl_pow(1.0f - cosine, 5.0f);
+}
+
+// refractVec, raytrace.comp.glsl:176-190
+__device__ __forceinline__ bool refract_vec(f3 incident, f3 normal, float eta, f3& refracted)
+{
+    float cos_theta = glsl_min(dot(-incident, normal), 1.0f);
+    f3 refract_perp = (incident + normal * cos_theta) * eta;
+    float perp_dot = dot(refract_perp, refract_perp);
+    if (perp_dot > 1.0f) {
+        return false;
+    }
+    f3 refract_parallel = normal * (-sqrtf(1.0f - perp_dot));
+    refracted = refract_perp + refract_parallel;
+    return true;
+}
+
+// rgba8 UNORM store conversion of imageStore(outputImage, ...), raytrace.comp.glsl:342
+__device__ __forceinline__ uint32_t unorm8(float c)
+{
+    float x = glsl_min(glsl_max(c, 0.0f), 1.0f);
+    return (uint32_t)floorf(x * 255.0f + 0.5f);
+}
+
+// Display tail, raytrace.comp.glsl:337-342, for one texel.
+__device__ __forceinline__ uint32_t tonemap_rgba8(f3 total, float sample_count)
+{
+    f3 color = total / sample_count;
+    color = mk(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));
+    const float inv_gamma = (float)(1.0 / 2.2);
+    uint32_t r = unorm8(glsl_pow(glsl_max(color.x, 0.0f), inv_gamma));
+    uint32_t g = unorm8(glsl_pow(glsl_max(color.y, 0.0f), inv_gamma));
+    uint32_t b = unorm8(glsl_pow(glsl_max(color.z, 0.0f), inv_gamma));
+    return r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+} // namespace rt

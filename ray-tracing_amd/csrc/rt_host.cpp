@@ -1,0 +1,840 @@
+// Host layer of the MI355X sphere path tracer: the C ABI of include/rt_mi355x.h.
+//
+// It keeps the state the reference keeps in class RayTracer
+// (src/rt/RayTracer.h:79-93): extent, reset flag, sphere list, camera, aperture,
+// field of view, focus distance, samples per frame and bounce budget; builds the
+// uniform block the way RayTracer::makeCameraParams does
+// (src/rt/RayTracer.cpp:140-177); and replaces the Vulkan recording of
+// RayTracer::render (:559-685) by a memset plus one kernel launch on a HIP stream.
+//
+// Compile with -ffp-contract=off: the camera block must come out with the bits
+// the reference's GLM code produces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_kernels.hpp"
+
+static_assert(sizeof(rt_gpu_sphere) == 48, "GPUSphere is 48 bytes (std430 stride)");
+static_assert(sizeof(rt_gpu_params) == 160, "GPUParams is 160 bytes (std140)");
+static_assert(offsetof(rt_gpu_params, frame_sample_depth_count) == 112, "uvec4 sits at byte 112");
+static_assert(offsetof(rt_gpu_params, resolution) == 128, "resolution sits at byte 128");
+static_assert(offsetof(rt_gpu_params, inv_resolution) == 144, "invResolution sits at byte 144");
+
+struct rt_tracer {
+    int device = 0;
+    uint32_t width = 0;
+    uint32_t height = 0;
+
+    float4* accum = nullptr;          // mAccumImage
+    uint32_t* output = nullptr;       // the swapchain image the shader stores into
+    rt_gpu_sphere* d_spheres = nullptr; // mSphereBuffer
+    uint32_t d_sphere_capacity = 0;
+    uint32_t* rng_state = nullptr;    // test hook
+    bool rng_capture = false;
+
+    bool reset_accum = true;          // mResetAccum
+    std::vector<rt_gpu_sphere> spheres; // mSpheres
+
+    // RayTracer.h:87-93
+    float cam_pos[3] = { 13.0f, 2.0f, 3.0f };
+    float cam_dir[3] = { -1.0f, 0.0f, 0.0f };
+    float aperture = 0.05f;
+    float vertical_fov = 20.0f;
+    float focus_distance = 10.0f;
+    uint32_t samples_per_pixel = 4;
+    uint32_t max_depth = 12;
+
+    hipEvent_t ev_start = nullptr;
+    hipEvent_t ev_stop = nullptr;
+    bool timed = false;
+
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// Mirrors VK_CHECK (src/util/Check.h:8-19): "<Result>(n) for <expr> at file:line".
+int fail_hip(rt_tracer* h, hipError_t e, const char* expr, const char* file, int line)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "hipError(%d: %s) for %s at %s:%d", (int)e, hipGetErrorName(e), expr, file, line);
+    if (h != nullptr) {
+        h->error = buf;
+    } else {
+        g_create_error = buf;
+    }
+    (void)hipGetLastError(); // clear the sticky per-thread error
+    return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP;
+}
+
+int fail_arg(rt_tracer* h, const char* what)
+{
+    if (h != nullptr) {
+        h->error = std::string("bad argument: ") + what;
+    } else {
+        g_create_error = std::string("bad argument: ") + what;
+    }
+    return RT_ERR_BAD_ARGUMENT;
+}
+
+#define RT_HIP_TRY(h, expr)                                              \
+    do {                                                                 \
+        hipError_t rt_e_ = (expr);                                       \
+        if (rt_e_ != hipSuccess) {                                       \
+            return fail_hip((h), rt_e_, #expr, __FILE__, __LINE__);      \
+        }                                                                \
+    } while (0)
+
+// Makes the handle's device current for the duration of one call and puts the
+// caller's device back afterwards.
+class DeviceScope {
+public:
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&previous_) != hipSuccess) {
+            previous_ = -1;
+        }
+        if (previous_ != device) {
+            status_ = hipSetDevice(device);
+            switched_ = (status_ == hipSuccess);
+        }
+    }
+    ~DeviceScope()
+    {
+        if (switched_ && previous_ >= 0) {
+            (void)hipSetDevice(previous_);
+        }
+    }
+    hipError_t status() const { return status_; }
+
+private:
+    int previous_ = -1;
+    bool switched_ = false;
+    hipError_t status_ = hipSuccess;
+};
+
+// ---- GLM 1.0.1 arithmetic used by RayTracer.cpp, restated in plain floats ----
+struct V3 {
+    float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline float dot3(V3 a, V3 b)
+{
+    // glm::dot: tmp = a * b; tmp.x + tmp.y + tmp.z
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+inline V3 normalize3(V3 a)
+{
+    // glm::normalize = v * inversesqrt(dot(v, v)); glm::inversesqrt = 1 / sqrt
+    float inv = 1.0f / std::sqrt(dot3(a, a));
+    return a * inv;
+}
+inline V3 cross3(V3 a, V3 b)
+{
+    return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+
+void set_sphere(rt_gpu_sphere& s, float cx, float cy, float cz, float r, float ar, float ag, float ab,
+                float mat, float fuzz, float ior, float flags)
+{
+    s.center_radius[0] = cx; s.center_radius[1] = cy; s.center_radius[2] = cz; s.center_radius[3] = r;
+    s.albedo[0] = ar; s.albedo[1] = ag; s.albedo[2] = ab; s.albedo[3] = 0.0f;
+    s.misc[0] = mat; s.misc[1] = fuzz; s.misc[2] = ior; s.misc[3] = flags;
+}
+
+// RayTracer::buildScene, src/rt/RayTracer.cpp:105-138
+void build_default_scene(std::vector<rt_gpu_sphere>& out)
+{
+    out.assign(5, rt_gpu_sphere{});
+    set_sphere(out[0], 0.0f, -1000.0f, 0.0f, 1000.0f, 0.75f, 0.8f, 0.9f, 0.0f, 0.0f, 1.0f, 1.0f); // ground, checker
+    set_sphere(out[1], 0.0f, 1.0f, 0.0f, 1.0f, 0.9f, 0.25f, 0.25f, 0.0f, 0.0f, 1.0f, 0.0f);       // centre, lambert
+    set_sphere(out[2], -4.0f, 1.0f, 0.0f, 1.0f, 1.0f, 1.0f, 1.0f, 2.0f, 0.0f, 1.5f, 0.0f);        // left, glass
+    set_sphere(out[3], 4.0f, 1.0f, 0.0f, 1.0f, 0.95f, 0.65f, 0.15f, 1.0f, 0.03f, 1.0f, 0.0f);     // right, fuzzy metal
+    set_sphere(out[4], 2.5f, 0.5f, 2.5f, 0.5f, 0.95f, 0.95f, 0.98f, 1.0f, 0.0f, 1.0f, 0.0f);      // mirror
+}
+
+// RayTracer::makeCameraParams, src/rt/RayTracer.cpp:140-177
+void make_camera_params(const rt_tracer& t, rt_gpu_params& params)
+{
+    const V3 look_from = v3(t.cam_pos[0], t.cam_pos[1], t.cam_pos[2]);
+    const V3 direction = normalize3(v3(t.cam_dir[0], t.cam_dir[1], t.cam_dir[2]));
+    const V3 look_at = look_from + direction;
+    const V3 vup = v3(0.0f, 1.0f, 0.0f);
+
+    const float aspect = static_cast<float>(t.width) / static_cast<float>(t.height);
+    const float theta = t.vertical_fov * 0.01745329251994329576923690768489f; // glm::radians
+    const float half_height = tanf(theta * 0.5f);
+    const float viewport_height = 2.0f * half_height;
+    const float viewport_width = aspect * viewport_height;
+
+    const V3 w = normalize3(look_from - look_at);
+    const V3 u = normalize3(cross3(vup, w));
+    const V3 v = cross3(w, u);
+
+    const float focus = t.focus_distance;
+    const V3 horizontal = u * (focus * viewport_width);
+    const V3 vertical = v * (focus * viewport_height);
+    const V3 lower_left = look_from - horizontal * 0.5f - vertical * 0.5f - w * focus;
+
+    std::memset(&params, 0, sizeof(params));
+    params.origin_lens[0] = look_from.x; params.origin_lens[1] = look_from.y; params.origin_lens[2] = look_from.z;
+    params.origin_lens[3] = t.aperture * 0.5f;
+    params.lower_left[0] = lower_left.x; params.lower_left[1] = lower_left.y; params.lower_left[2] = lower_left.z;
+    params.horizontal[0] = horizontal.x; params.horizontal[1] = horizontal.y; params.horizontal[2] = horizontal.z;
+    params.vertical[0] = vertical.x; params.vertical[1] = vertical.y; params.vertical[2] = vertical.z;
+    params.u[0] = u.x; params.u[1] = u.y; params.u[2] = u.z;
+    params.v[0] = v.x; params.v[1] = v.y; params.v[2] = v.z;
+    params.w[0] = w.x; params.w[1] = w.y; params.w[2] = w.z;
+    params.resolution[0] = static_cast<float>(t.width);
+    params.resolution[1] = static_cast<float>(t.height);
+    params.inv_resolution[0] = 1.0f / static_cast<float>(t.width);
+    params.inv_resolution[1] = 1.0f / static_cast<float>(t.height);
+}
+
+// RayTracer::updateParams, src/rt/RayTracer.cpp:550-557
+void update_params(const rt_tracer& t, uint32_t frame_index, rt_gpu_params& params)
+{
+    make_camera_params(t, params);
+    params.frame_sample_depth_count[0] = frame_index;
+    params.frame_sample_depth_count[1] = t.samples_per_pixel;
+    params.frame_sample_depth_count[2] = t.max_depth;
+    params.frame_sample_depth_count[3] = static_cast<uint32_t>(t.spheres.size());
+}
+
+void free_images(rt_tracer* h)
+{
+    if (h->accum) { (void)hipFree(h->accum); h->accum = nullptr; }
+    if (h->output) { (void)hipFree(h->output); h->output = nullptr; }
+    if (h->rng_state) { (void)hipFree(h->rng_state); h->rng_state = nullptr; }
+}
+
+// RayTracer::createAccumulationImage, src/rt/RayTracer.cpp:498-527 (+ the output image
+// that the reference borrows from the swapchain)
+int allocate_images(rt_tracer* h)
+{
+    const size_t pixels = static_cast<size_t>(h->width) * h->height;
+    RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->accum), pixels * sizeof(float4)));
+    RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->output), pixels * sizeof(uint32_t)));
+    RT_HIP_TRY(h, hipMemset(h->output, 0, pixels * sizeof(uint32_t)));
+    if (h->rng_capture) {
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->rng_state), pixels * sizeof(uint32_t)));
+    }
+    return RT_OK;
+}
+
+// RayTracer::uploadScene, src/rt/RayTracer.cpp:529-548
+int upload_scene(rt_tracer* h, hipStream_t stream)
+{
+    const uint32_t n = static_cast<uint32_t>(h->spheres.size());
+    if (n > h->d_sphere_capacity) {
+        // the previous buffer may still be read by a kernel in flight
+        RT_HIP_TRY(h, hipDeviceSynchronize());
+        if (h->d_spheres) {
+            (void)hipFree(h->d_spheres);
+            h->d_spheres = nullptr;
+            h->d_sphere_capacity = 0;
+        }
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_spheres), n * sizeof(rt_gpu_sphere)));
+        h->d_sphere_capacity = n;
+    }
+    // pageable-memory copy: returns once the source has been staged, ordered on the stream
+    RT_HIP_TRY(h, hipMemcpyAsync(h->d_spheres, h->spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice, stream));
+    RT_HIP_TRY(h, hipStreamSynchronize(stream));
+    return RT_OK;
+}
+
+// RayTracer::create, src/rt/RayTracer.cpp:188-193: default scene and the create-time aim
+void init_default_state(rt_tracer* h)
+{
+    build_default_scene(h->spheres);
+    const V3 look_at = v3(0.0f, 1.0f, 0.0f);
+    const V3 pos = v3(h->cam_pos[0], h->cam_pos[1], h->cam_pos[2]);
+    const V3 d = look_at - pos;
+    const V3 nd = normalize3(d);
+    h->cam_dir[0] = nd.x; h->cam_dir[1] = nd.y; h->cam_dir[2] = nd.z;
+    h->focus_distance = std::sqrt(dot3(d, d)); // glm::length
+}
+
+int fail_no_device(rt_tracer* h)
+{
+    h->error = "handle was created with RT_DEVICE_NONE: it holds host state only";
+    return RT_ERR_NO_DEVICE;
+}
+
+#define RT_NEED_DEVICE(h)                  \
+    do {                                   \
+        if ((h)->device < 0) {             \
+            return fail_no_device(h);      \
+        }                                  \
+    } while (0)
+
+bool valid_extent(uint32_t w, uint32_t hgt)
+{
+    return w >= 1 && hgt >= 1 && w <= 65536u && hgt <= 65536u;
+}
+
+int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                uint32_t row_begin, uint32_t row_end, bool write_output, hipStream_t stream)
+{
+    if (row_begin > row_end || row_end > h->height) {
+        return fail_arg(h, "row range outside the image");
+    }
+    RT_NEED_DEVICE(h);
+    if (n_frames == 0) {
+        return RT_OK;
+    }
+    if (frame_stride == 0) {
+        return fail_arg(h, "frame_stride must be >= 1");
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+
+    // RayTracer::render, src/rt/RayTracer.cpp:564-603
+    const bool clear_accum = h->reset_accum || first_frame == 0;
+    if (clear_accum) {
+        const size_t bytes = static_cast<size_t>(h->width) * h->height * sizeof(float4);
+        RT_HIP_TRY(h, hipMemsetAsync(h->accum, 0, bytes, stream));
+        h->reset_accum = false;
+    }
+
+    rt::TraceArgs args;
+    update_params(*h, first_frame, args.params);
+    args.accum = h->accum;
+    args.output = write_output ? h->output : nullptr;
+    args.spheres = h->d_spheres;
+    args.rng_out = h->rng_capture ? h->rng_state : nullptr;
+    args.width = h->width;
+    args.height = h->height;
+    args.row_begin = row_begin;
+    args.row_end = row_end;
+    args.first_frame = first_frame;
+    args.n_frames = n_frames;
+    args.frame_stride = frame_stride;
+
+    RT_HIP_TRY(h, hipEventRecord(h->ev_start, stream));
+    RT_HIP_TRY(h, rt::launch_trace(args, stream));
+    RT_HIP_TRY(h, hipEventRecord(h->ev_stop, stream));
+    h->timed = true;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
+{
+    if (out == nullptr) {
+        return fail_arg(nullptr, "out is NULL");
+    }
+    *out = nullptr;
+    if (!valid_extent(width, height)) {
+        return fail_arg(nullptr, "extent must be within 1..65536");
+    }
+    if (device_id != RT_DEVICE_NONE) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0) {
+            g_create_error = "no HIP device available";
+            (void)hipGetLastError();
+            return RT_ERR_NO_DEVICE;
+        }
+        if (device_id < 0 || device_id >= count) {
+            return fail_arg(nullptr, "device_id out of range");
+        }
+    }
+    rt_tracer* h = new (std::nothrow) rt_tracer();
+    if (h == nullptr) {
+        g_create_error = "host allocation failed";
+        return RT_ERR_OUT_OF_MEMORY;
+    }
+    h->device = device_id;
+    h->width = width;
+    h->height = height;
+    h->reset_accum = true;
+    init_default_state(h);
+    if (device_id == RT_DEVICE_NONE) {
+        // host-state-only handle: setters, rt_get_params and rt_get_spheres work, nothing renders
+        *out = h;
+        return RT_OK;
+    }
+
+    int rc = RT_OK;
+    {
+        DeviceScope scope(device_id);
+        auto body = [&]() -> int {
+            RT_HIP_TRY(h, scope.status());
+            RT_HIP_TRY(h, hipEventCreate(&h->ev_start));
+            RT_HIP_TRY(h, hipEventCreate(&h->ev_stop));
+            int r = upload_scene(h, nullptr);
+            if (r != RT_OK) {
+                return r;
+            }
+            return allocate_images(h);
+        };
+        rc = body();
+    }
+    if (rc != RT_OK) {
+        g_create_error = h->error;
+        rt_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return RT_OK;
+}
+
+int rt_resize(rt_handle h, uint32_t width, uint32_t height)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (!valid_extent(width, height)) {
+        return fail_arg(h, "extent must be within 1..65536");
+    }
+    if (h->device < 0) {
+        h->width = width;
+        h->height = height;
+        h->reset_accum = true;
+        return RT_OK;
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    RT_HIP_TRY(h, hipDeviceSynchronize()); // vkDeviceWaitIdle, :203
+    free_images(h);
+    h->width = width;
+    h->height = height;
+    h->reset_accum = true; // :228
+    h->timed = false;
+    return allocate_images(h);
+}
+
+int rt_destroy(rt_handle h)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (h->device >= 0) {
+        DeviceScope scope(h->device);
+        (void)hipDeviceSynchronize(); // vkDeviceWaitIdle, :238
+        free_images(h);
+        if (h->d_spheres) { (void)hipFree(h->d_spheres); }
+        if (h->ev_start) { (void)hipEventDestroy(h->ev_start); }
+        if (h->ev_stop) { (void)hipEventDestroy(h->ev_stop); }
+        (void)hipGetLastError();
+    }
+    delete h;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_handle h, const float pos[3], const float dir[3], float focus_dist)
+{
+    if (h == nullptr || pos == nullptr || dir == nullptr) {
+        return h ? fail_arg(h, "pos/dir is NULL") : RT_ERR_BAD_ARGUMENT;
+    }
+    h->cam_pos[0] = pos[0]; h->cam_pos[1] = pos[1]; h->cam_pos[2] = pos[2];
+    const V3 nd = normalize3(v3(dir[0], dir[1], dir[2]));
+    h->cam_dir[0] = nd.x; h->cam_dir[1] = nd.y; h->cam_dir[2] = nd.z;
+    if (focus_dist > 0.0f) {
+        h->focus_distance = focus_dist;
+    }
+    h->reset_accum = true;
+    return RT_OK;
+}
+
+int rt_set_samples_per_pixel(rt_handle h, uint32_t spp)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->samples_per_pixel = std::max(1u, spp);
+    h->reset_accum = true;
+    return RT_OK;
+}
+
+int rt_set_aperture(rt_handle h, float aperture)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->aperture = std::max(0.0f, aperture);
+    h->reset_accum = true;
+    return RT_OK;
+}
+
+int rt_set_focus_distance(rt_handle h, float focus_dist)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (focus_dist > 0.0f) {
+        h->focus_distance = focus_dist;
+        h->reset_accum = true;
+    }
+    return RT_OK;
+}
+
+int rt_set_fov(rt_handle h, float vfov_deg)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->vertical_fov = std::clamp(vfov_deg, 5.0f, 120.0f);
+    h->reset_accum = true;
+    return RT_OK;
+}
+
+int rt_set_max_depth(rt_handle h, uint32_t depth)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->max_depth = std::max(1u, depth);
+    h->reset_accum = true;
+    return RT_OK;
+}
+
+int rt_set_spheres(rt_handle h, const rt_gpu_sphere* spheres, uint32_t n)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (spheres == nullptr || n == 0) {
+        return fail_arg(h, "sphere list is empty");
+    }
+    if (n > rt::kMaxSpheres) {
+        return fail_arg(h, "more than 4096 spheres");
+    }
+    h->spheres.assign(spheres, spheres + n);
+    h->reset_accum = true;
+    if (h->device < 0) {
+        return RT_OK;
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    return upload_scene(h, nullptr);
+}
+
+int rt_get_spheres(rt_handle h, rt_gpu_sphere* out, uint32_t cap, uint32_t* n)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    const uint32_t count = static_cast<uint32_t>(h->spheres.size());
+    if (n != nullptr) {
+        *n = count;
+    }
+    if (out != nullptr) {
+        std::memcpy(out, h->spheres.data(), sizeof(rt_gpu_sphere) * std::min(cap, count));
+    }
+    return RT_OK;
+}
+
+int rt_get_params(rt_handle h, uint32_t frame_index, rt_gpu_params* out)
+{
+    if (h == nullptr || out == nullptr) {
+        return h ? fail_arg(h, "out is NULL") : RT_ERR_BAD_ARGUMENT;
+    }
+    update_params(*h, frame_index, *out);
+    return RT_OK;
+}
+
+int rt_reset_accumulation(rt_handle h)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->reset_accum = true;
+    return RT_OK;
+}
+
+int rt_render(rt_handle h, uint32_t frame_index, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    return render_impl(h, frame_index, 1, 1, 0, h->height, true, static_cast<hipStream_t>(stream));
+}
+
+int rt_render_frames(rt_handle h, uint32_t first_frame, uint32_t n_frames, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    return render_impl(h, first_frame, n_frames, 1, 0, h->height, true, static_cast<hipStream_t>(stream));
+}
+
+int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                    uint32_t row_begin, uint32_t row_end, int write_output, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    return render_impl(h, first_frame, n_frames, frame_stride, row_begin, row_end, write_output != 0,
+                       static_cast<hipStream_t>(stream));
+}
+
+int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    if (row_begin > row_end || row_end > h->height) {
+        return fail_arg(h, "row range outside the image");
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    const uint64_t first = static_cast<uint64_t>(row_begin) * h->width;
+    const uint64_t count = static_cast<uint64_t>(row_end - row_begin) * h->width;
+    if (first + count > 0xFFFFFFFFull) {
+        return fail_arg(h, "image too large for the resolve kernel");
+    }
+    RT_HIP_TRY(h, rt::launch_resolve(h->accum, h->output, static_cast<uint32_t>(first), static_cast<uint32_t>(count),
+                                     static_cast<float>(sample_count), static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+void* rt_accum_device_ptr(rt_handle h) { return h ? h->accum : nullptr; }
+void* rt_output_device_ptr(rt_handle h) { return h ? h->output : nullptr; }
+
+int rt_read_accum(rt_handle h, float* host, size_t bytes, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    if (host == nullptr || bytes != static_cast<size_t>(h->width) * h->height * sizeof(float4)) {
+        return fail_arg(h, "accumulator copy needs width*height*16 bytes");
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    RT_HIP_TRY(h, hipMemcpyAsync(host, h->accum, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    RT_HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int rt_write_accum(rt_handle h, const float* host, size_t bytes, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    if (host == nullptr || bytes != static_cast<size_t>(h->width) * h->height * sizeof(float4)) {
+        return fail_arg(h, "accumulator copy needs width*height*16 bytes");
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    RT_HIP_TRY(h, hipMemcpyAsync(h->accum, host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    RT_HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int rt_read_output(rt_handle h, uint8_t* host, size_t bytes, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    if (host == nullptr || bytes != static_cast<size_t>(h->width) * h->height * sizeof(uint32_t)) {
+        return fail_arg(h, "output copy needs width*height*4 bytes");
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    RT_HIP_TRY(h, hipMemcpyAsync(host, h->output, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    RT_HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int rt_enable_rng_capture(rt_handle h, int enable)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    if (enable && h->rng_state == nullptr) {
+        const size_t pixels = static_cast<size_t>(h->width) * h->height;
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->rng_state), pixels * sizeof(uint32_t)));
+        RT_HIP_TRY(h, hipMemset(h->rng_state, 0, pixels * sizeof(uint32_t)));
+    }
+    h->rng_capture = enable != 0;
+    return RT_OK;
+}
+
+int rt_read_rng_state(rt_handle h, uint32_t* host, size_t bytes, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    if (h->rng_state == nullptr) {
+        return fail_arg(h, "RNG capture was never enabled");
+    }
+    if (host == nullptr || bytes != static_cast<size_t>(h->width) * h->height * sizeof(uint32_t)) {
+        return fail_arg(h, "RNG state copy needs width*height*4 bytes");
+    }
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    RT_HIP_TRY(h, hipMemcpyAsync(host, h->rng_state, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    RT_HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int rt_synchronize(rt_handle h, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    RT_NEED_DEVICE(h);
+    DeviceScope scope(h->device);
+    RT_HIP_TRY(h, scope.status());
+    RT_HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return RT_OK;
+}
+
+int rt_get_extent(rt_handle h, uint32_t* width, uint32_t* height)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (width) { *width = h->width; }
+    if (height) { *height = h->height; }
+    return RT_OK;
+}
+
+float rt_last_kernel_ms(rt_handle h)
+{
+    if (h == nullptr || !h->timed || h->device < 0) {
+        return -1.0f;
+    }
+    DeviceScope scope(h->device);
+    if (hipEventSynchronize(h->ev_stop) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0f;
+    }
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev_start, h->ev_stop) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0f;
+    }
+    return ms;
+}
+
+const char* rt_last_error(rt_handle h)
+{
+    if (h == nullptr) {
+        return g_create_error.c_str();
+    }
+    return h->error.c_str();
+}
+
+} // extern "C"
+
+// ---- device-side probes of single shader functions (vector tests) ----
+namespace {
+
+template <typename Body>
+int with_device(int device_id, Body body)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        g_create_error = "no HIP device available";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) {
+        return fail_arg(nullptr, "device_id out of range");
+    }
+    DeviceScope scope(device_id);
+    if (scope.status() != hipSuccess) {
+        return fail_hip(nullptr, scope.status(), "hipSetDevice", __FILE__, __LINE__);
+    }
+    return body();
+}
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    ~DeviceBuffer() { if (ptr) { (void)hipFree(ptr); } }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes ? bytes : 1); }
+};
+
+} // namespace
+
+extern "C" {
+
+int rt_probe_hit_sphere(int device_id, const rt_gpu_sphere* spheres, const float* rays, uint32_t n, float* out, int32_t* front)
+{
+    if (!spheres || !rays || !out || !front || n == 0) {
+        return fail_arg(nullptr, "probe arguments");
+    }
+    return with_device(device_id, [&]() -> int {
+        DeviceBuffer ds, dr, dout, df;
+        rt_tracer* none = nullptr;
+        RT_HIP_TRY(none, ds.alloc(n * sizeof(rt_gpu_sphere)));
+        RT_HIP_TRY(none, dr.alloc(n * 8 * sizeof(float)));
+        RT_HIP_TRY(none, dout.alloc(n * 8 * sizeof(float)));
+        RT_HIP_TRY(none, df.alloc(n * sizeof(int32_t)));
+        RT_HIP_TRY(none, hipMemcpy(ds.ptr, spheres, n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, hipMemcpy(dr.ptr, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, rt::launch_probe_hit(static_cast<rt_gpu_sphere*>(ds.ptr), static_cast<float*>(dr.ptr), n,
+                                              static_cast<float*>(dout.ptr), static_cast<int32_t*>(df.ptr), nullptr));
+        RT_HIP_TRY(none, hipMemcpy(out, dout.ptr, n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+        RT_HIP_TRY(none, hipMemcpy(front, df.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+int rt_probe_pow(int device_id, const float* x, const float* y, uint32_t n, float* out)
+{
+    if (!x || !y || !out || n == 0) {
+        return fail_arg(nullptr, "probe arguments");
+    }
+    return with_device(device_id, [&]() -> int {
+        DeviceBuffer dx, dy, dout;
+        rt_tracer* none = nullptr;
+        RT_HIP_TRY(none, dx.alloc(n * sizeof(float)));
+        RT_HIP_TRY(none, dy.alloc(n * sizeof(float)));
+        RT_HIP_TRY(none, dout.alloc(n * sizeof(float)));
+        RT_HIP_TRY(none, hipMemcpy(dx.ptr, x, n * sizeof(float), hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, hipMemcpy(dy.ptr, y, n * sizeof(float), hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, rt::launch_probe_pow(static_cast<float*>(dx.ptr), static_cast<float*>(dy.ptr), n,
+                                              static_cast<float*>(dout.ptr), nullptr));
+        RT_HIP_TRY(none, hipMemcpy(out, dout.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+int rt_probe_rng(int device_id, const uint32_t* xyz, uint32_t n, uint32_t draws, uint32_t* out)
+{
+    if (!xyz || !out || n == 0) {
+        return fail_arg(nullptr, "probe arguments");
+    }
+    return with_device(device_id, [&]() -> int {
+        DeviceBuffer din, dout;
+        rt_tracer* none = nullptr;
+        const size_t out_bytes = static_cast<size_t>(n) * (1 + draws) * sizeof(uint32_t);
+        RT_HIP_TRY(none, din.alloc(n * 3 * sizeof(uint32_t)));
+        RT_HIP_TRY(none, dout.alloc(out_bytes));
+        RT_HIP_TRY(none, hipMemcpy(din.ptr, xyz, n * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, rt::launch_probe_rng(static_cast<uint32_t*>(din.ptr), n, draws, static_cast<uint32_t*>(dout.ptr), nullptr));
+        RT_HIP_TRY(none, hipMemcpy(out, dout.ptr, out_bytes, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,46 @@
+// Launch interface between the host layer (rt_host.cpp) and the HIP kernels
+// (rt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/rt_mi355x.h"
+
+namespace rt {
+
+// Largest sphere count whose full 48-byte records are staged in LDS.
+constexpr uint32_t kMaxSpheresFullLds = 1024;
+// Largest sphere count the tracer accepts (16-byte geometry records: 64 KiB of LDS).
+constexpr uint32_t kMaxSpheres = 4096;
+
+// Kernel arguments of one trace launch.  `params` is the reference's uniform
+// block (raytrace.comp.glsl:19-31) passed by value, so it lands in scalar
+// registers; params.frame_sample_depth_count[0] is ignored in favour of
+// first_frame/frame_stride.
+struct TraceArgs {
+    rt_gpu_params params;
+    float4* accum;               // binding 0, float4 per pixel, pitch = width
+    uint32_t* output;            // binding 1, rgba8 per pixel, or nullptr to skip the display tail
+    const rt_gpu_sphere* spheres; // binding 2
+    uint32_t* rng_out;           // optional per-pixel final RNG state
+    uint32_t width;
+    uint32_t height;
+    uint32_t row_begin;
+    uint32_t row_end;
+    uint32_t first_frame;
+    uint32_t n_frames;
+    uint32_t frame_stride;
+};
+
+size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds);
+hipError_t launch_trace(const TraceArgs& args, hipStream_t stream);
+hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first, uint32_t count,
+                          float sample_count, hipStream_t stream);
+hipError_t launch_probe_hit(const rt_gpu_sphere* spheres, const float* rays, uint32_t n, float* out,
+                            int32_t* front, hipStream_t stream);
+hipError_t launch_probe_pow(const float* x, const float* y, uint32_t n, float* out, hipStream_t stream);
+hipError_t launch_probe_rng(const uint32_t* xyz, uint32_t n, uint32_t draws, uint32_t* out, hipStream_t stream);
+
+} // namespace rt

@@ -1,0 +1,266 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, bit for bit: RNG words, accumulator
+floats, rgba8 bytes.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def oracle_frames(oracle, tracer, scene, frames, row_begin=0, row_end=None, accum=None, want_rng=False):
+    """Runs the oracle for the given frame indices with the tracer's own uniform block."""
+    out = None
+    for f in frames:
+        words = tracer.get_params_words(f)
+        out = oracle.render(words, scene, accum=accum, y0=row_begin, y1=row_end, want_rng=want_rng)
+        accum = out["accum"]
+    return out
+
+
+def make_tracer(pkg, w, h, spp=2, depth=8, aperture=0.05, scene=None):
+    t = pkg.RayTracer().create(w, h, device_id=0)
+    t.set_samples_per_pixel(spp)
+    t.set_max_depth(depth)
+    t.set_aperture(aperture)
+    if scene is not None:
+        t.set_spheres(scene)
+    return t
+
+
+def test_rng_words_match_known_answers(pkg, oracle, golden_dir):
+    import json
+    import os
+    kat = json.load(open(os.path.join(golden_dir, "rng_kat.json")))
+    xyz = np.array([r["xyz"] for r in kat], dtype=np.uint32)
+    got = pkg.probe_rng(xyz, 8)
+    for i, rec in enumerate(kat):
+        assert int(got[i, 0]) == rec["hash"]
+        assert [int(v) for v in got[i, 1:]] == rec["lcg"]
+    # and a random batch against the oracle
+    rng = np.random.default_rng(3)
+    xyz = rng.integers(0, 2**32, size=(4096, 3), dtype=np.uint64).astype(np.uint32)
+    got = pkg.probe_rng(xyz, 4)
+    for i in range(0, 4096, 97):
+        h = oracle.hash3(int(xyz[i, 0]), int(xyz[i, 1]), int(xyz[i, 2]))
+        assert int(got[i, 0]) == h
+        assert [int(v) for v in got[i, 1:]] == oracle.lcg_sequence(h, 4)
+
+
+def test_pow_bits_match_oracle(pkg, oracle):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(20000, dtype=np.float32),
+                        np.float32([0.0, 1.0, 0.5, 1e-6, 1e-30, 1e-42, 0.99999994, 2.0, 100.0])])
+    for yv in (5.0, float(np.float32(1.0 / 2.2))):
+        y = np.full_like(x, yv)
+        got = pkg.probe_pow(x, y)
+        want = np.array([oracle.lib().rto_powf(float(a), float(b)) for a, b in zip(x, y)], dtype=np.float32)
+        assert np.array_equal(bits(got), bits(want))
+
+
+def test_hit_sphere_vectors(pkg, oracle):
+    rng = np.random.default_rng(7)
+    n = 6000
+    scene = pkg.default_scene()
+    spheres = scene[rng.integers(0, 5, size=n)]
+    o = rng.normal(size=(n, 3)).astype(np.float32) * np.float32(3.0) + np.float32([0, 1, 0])
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True).astype(np.float32)
+    # half of the rays start on a sphere surface heading away/inwards (the far-root branch)
+    c = spheres[:, :3]
+    r = spheres[:, 3:4]
+    o[n // 3:] = (c[n // 3:] + r[n // 3:] * d[n // 3:] /
+                  np.linalg.norm(d[n // 3:], axis=1, keepdims=True)).astype(np.float32)
+    tmax = np.where(rng.random(n) < 0.5, np.float32(1e20), rng.random(n).astype(np.float32) * np.float32(20.0))
+    rays = np.zeros((n, 8), dtype=np.float32)
+    rays[:, 0:3] = o
+    rays[:, 3] = 0.001
+    rays[:, 4:7] = d
+    rays[:, 7] = tmax
+    out, front = pkg.probe_hit_sphere(spheres, rays)
+    hits = 0
+    for i in range(n):
+        ref = oracle.hit_sphere(spheres[i], rays[i, 0:3], rays[i, 4:7], 0.001, float(tmax[i]))
+        if ref is None:
+            assert out[i, 0] == 0.0
+            continue
+        hits += 1
+        assert out[i, 0] == 1.0
+        want = np.float32([ref["t"]] + ref["p"] + ref["n"])
+        assert np.array_equal(bits(out[i, 1:8]), bits(want)), i
+        assert bool(front[i]) == ref["front"]
+    assert hits > n // 10
+
+
+@pytest.mark.parametrize("w,h,spp,depth,aperture", [
+    (64, 64, 1, 8, 0.05),
+    (200, 120, 4, 8, 0.0),      # DoF off: the lens draws are still consumed
+    (67, 45, 3, 1, 0.05),       # ragged extent, one bounce
+    (1, 1, 16, 12, 0.2),
+    (9, 130, 2, 50, 0.05),
+])
+def test_single_frame_bit_exact(pkg, oracle, w, h, spp, depth, aperture):
+    t = make_tracer(pkg, w, h, spp, depth, aperture)
+    t.enable_rng_capture(True)
+    t.render(0)
+    got_acc, got_out, got_rng = t.read_accum(), t.read_output(), t.read_rng_state()
+    ref = oracle_frames(oracle, t, pkg.default_scene(), [0], want_rng=True)
+    assert np.array_equal(got_rng, ref["rng"]), "per-pixel RNG streams diverged"
+    assert np.array_equal(bits(got_acc), bits(ref["accum"]))
+    assert np.array_equal(got_out, ref["output"])
+    t.destroy()
+
+
+def test_accumulate_frames_sequential_and_batched(pkg, oracle):
+    w, h = 160, 90
+    scene = pkg.default_scene()
+    seq = make_tracer(pkg, w, h, 2, 8)
+    for f in range(5):
+        seq.render(f)
+    bat = make_tracer(pkg, w, h, 2, 8)
+    bat.enable_rng_capture(True)
+    bat.render_frames(0, 5)
+    ref = oracle_frames(oracle, seq, scene, range(5), want_rng=True)
+    assert np.array_equal(bits(seq.read_accum()), bits(ref["accum"]))
+    assert np.array_equal(bits(bat.read_accum()), bits(ref["accum"]))
+    assert np.array_equal(bat.read_rng_state(), ref["rng"])
+    assert np.array_equal(seq.read_output(), ref["output"])
+    assert np.array_equal(bat.read_output(), ref["output"])
+    # continuing the accumulation from frame 5 without a reset
+    bat.render_frames(5, 2)
+    ref2 = oracle_frames(oracle, seq, scene, [5, 6], accum=ref["accum"].copy())
+    assert np.array_equal(bits(bat.read_accum()), bits(ref2["accum"]))
+    seq.destroy()
+    bat.destroy()
+
+
+def test_reset_on_change_semantics(pkg, oracle):
+    # RayTracer::render clears iff the flag is up or frame_index == 0 (src/rt/RayTracer.cpp:564)
+    w, h = 48, 32
+    scene = pkg.default_scene()
+    t = make_tracer(pkg, w, h, 1, 4)
+    t.render(0)
+    t.render(1)
+    two = t.read_accum()
+    t.render(0)                      # frame 0 clears
+    one = t.read_accum()
+    ref0 = oracle_frames(oracle, t, scene, [0])
+    assert np.array_equal(bits(one), bits(ref0["accum"]))
+    assert not np.array_equal(bits(one), bits(two))
+    t.set_fov(30.0)                  # any setter raises the flag ...
+    t.render(3)                      # ... so frame 3 starts from a cleared accumulator (the App.cpp:424-448 quirk)
+    ref3 = oracle_frames(oracle, t, scene, [3])
+    assert np.array_equal(bits(t.read_accum()), bits(ref3["accum"]))
+    assert np.array_equal(t.read_output(), ref3["output"])   # divisor is (3+1)*spp
+    t.render(4)                      # flag is down again: accumulates
+    ref34 = oracle_frames(oracle, t, scene, [4], accum=ref3["accum"].copy())
+    assert np.array_equal(bits(t.read_accum()), bits(ref34["accum"]))
+    t.set_focus_distance(-1.0)       # ignored: does not raise the flag
+    t.render(5)
+    ref345 = oracle_frames(oracle, t, scene, [5], accum=ref34["accum"].copy())
+    assert np.array_equal(bits(t.read_accum()), bits(ref345["accum"]))
+    t.destroy()
+
+
+def test_resize_reallocates_and_resets(pkg, oracle):
+    t = make_tracer(pkg, 40, 40, 1, 4)
+    t.render(0)
+    t.resize(72, 24)
+    assert t.extent == (72, 24)
+    t.render(2)
+    ref = oracle_frames(oracle, t, pkg.default_scene(), [2])
+    assert np.array_equal(bits(t.read_accum()), bits(ref["accum"]))
+    t.destroy()
+
+
+def test_row_band_shards_equal_whole_image(pkg, oracle):
+    w, h = 96, 70
+    t = make_tracer(pkg, w, h, 2, 8)
+    t.render_frames(0, 3)
+    whole = t.read_accum()
+    whole_out = t.read_output()
+    s = make_tracer(pkg, w, h, 2, 8)
+    for (a, b) in [(0, 9), (9, 41), (41, 70)]:
+        s.render_shard(0, 3, 1, a, b)
+    assert np.array_equal(bits(s.read_accum()), bits(whole))
+    assert np.array_equal(s.read_output(), whole_out)
+    t.destroy()
+    s.destroy()
+
+
+def test_frame_stride_shards(pkg, oracle):
+    # frame-index split: two "ranks" take even and odd frames; the RNG streams stay those of the
+    # single-GPU run, the sum differs from the sequential one only by float association
+    w, h = 80, 60
+    scene = pkg.default_scene()
+    even = make_tracer(pkg, w, h, 2, 8)
+    odd = make_tracer(pkg, w, h, 2, 8)
+    even.render_shard(0, 4, 2, 0, h, write_output=False)
+    odd.render_shard(1, 4, 2, 0, h, write_output=False)
+    ref_even = oracle_frames(oracle, even, scene, [0, 2, 4, 6])
+    ref_odd = oracle_frames(oracle, even, scene, [1, 3, 5, 7])
+    assert np.array_equal(bits(even.read_accum()), bits(ref_even["accum"]))
+    assert np.array_equal(bits(odd.read_accum()), bits(ref_odd["accum"]))
+    seq = oracle_frames(oracle, even, scene, range(8))
+    summed = ref_even["accum"][..., :3] + ref_odd["accum"][..., :3]
+    lum = seq["accum"][..., :3].mean()
+    rmse = np.sqrt(np.mean((summed - seq["accum"][..., :3]) ** 2))
+    assert rmse <= 1e-3 * lum
+    # resolve after the "reduction": write the sum back and run the display tail alone
+    total = np.concatenate([summed, np.ones((h, w, 1), dtype=np.float32)], axis=2)
+    even.write_accum(total)
+    even.resolve_output(8 * 2)
+    words = even.get_params_words(7)
+    ref = oracle.render(words, scene, accum=None)  # only to obtain an output buffer of the right shape
+    # oracle tonemap of `total`: re-run frame 7's tail by rendering zero extra radiance is not possible,
+    # so compare with the sequential image within one 8-bit step
+    diff = np.abs(even.read_output().astype(np.int32) - seq["output"].astype(np.int32))
+    assert diff.max() <= 1
+    even.destroy()
+    odd.destroy()
+
+
+@pytest.mark.parametrize("count", [2, 64, 1024, 1500, 4096])
+def test_custom_scenes(pkg, oracle, count):
+    # 1500 and 4096 spheres exercise the geometry-only LDS layout (materials fetched from global memory)
+    scene = pkg.synthetic_scene(count)
+    w, h = (48, 32) if count > 1024 else (80, 48)
+    t = make_tracer(pkg, w, h, 2, 6, 0.05, scene=scene)
+    t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
+    t.enable_rng_capture(True)
+    t.render_frames(0, 2)
+    ref = oracle_frames(oracle, t, scene, [0, 1], want_rng=True)
+    assert np.array_equal(t.read_rng_state(), ref["rng"])
+    assert np.array_equal(bits(t.read_accum()), bits(ref["accum"]))
+    assert np.array_equal(t.read_output(), ref["output"])
+    t.destroy()
+
+
+def test_full_1080p_frame_bit_exact(pkg, oracle):
+    # the benchmark configuration (1920x1080, 16 spp, depth 8, DoF off), one frame
+    t = make_tracer(pkg, 1920, 1080, 16, 8, 0.0)
+    t.enable_rng_capture(True)
+    t.render(0)
+    ref = oracle_frames(oracle, t, pkg.default_scene(), [0], want_rng=True)
+    assert np.array_equal(t.read_rng_state(), ref["rng"])
+    assert np.array_equal(bits(t.read_accum()), bits(ref["accum"]))
+    assert np.array_equal(t.read_output(), ref["output"])
+    t.destroy()
+
+
+def test_converged_radiance_properties(pkg, oracle):
+    # size-independent checks at 4096 spp on a small image: alpha is 1, radiance is finite and
+    # non-negative, and the mean luminance agrees with an independent 256-spp oracle render of
+    # other frame indices (different random streams) within Monte-Carlo noise
+    w, h = 64, 36
+    t = make_tracer(pkg, w, h, 64, 8)
+    t.render_frames(0, 64)
+    acc = t.read_accum()
+    assert np.all(acc[..., 3] == 1.0) and np.all(np.isfinite(acc)) and np.all(acc[..., :3] >= 0.0)
+    mean_gpu = acc[..., :3].mean() / 4096.0
+    ref = oracle_frames(oracle, t, pkg.default_scene(), range(100, 104))
+    mean_ref = ref["accum"][..., :3].mean() / 256.0
+    assert abs(mean_gpu - mean_ref) <= 0.02 * mean_ref
+    t.destroy()

@@ -123,8 +123,10 @@ int rt_render_frames(rt_handle h, uint32_t first_frame, uint32_t n_frames, void 
 /* The sharded form of rt_render_frames used across GPUs: renders frames
  * first_frame, first_frame + frame_stride, ... (n_frames of them) for rows
  * [row_begin, row_end) only.  Pixel coordinates stay global, so every texel
- * gets the same RNG stream as on one GPU (raytrace.comp.glsl:310-311).  The
- * clear rule is that of rt_render applied to first_frame.  With
+ * gets the same RNG stream as on one GPU (raytrace.comp.glsl:310-311).  Clear
+ * rule: a raised reset flag clears the whole image (and is lowered);
+ * first_frame == 0 clears rows [row_begin,row_end) only, so the bands of one
+ * image can be rendered by successive calls.  With
  * write_output == 0 the rgba8 image is left untouched (a frame-split rank
  * resolves it after the reduction with rt_resolve_output). */
 int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
@@ -135,6 +137,10 @@ int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32
  * stores rgba8 for rows [row_begin,row_end).  sample_count is the shader's
  * (frame + 1) * spp. */
 int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *stream);
+/* The same, reading a caller-owned float4 image of the handle's extent (e.g. the
+ * buffer a multi-GPU sum-reduction of accumulators landed in). */
+int rt_resolve_output_from(rt_handle h, const void *accum_device, uint32_t sample_count, uint32_t row_begin,
+                           uint32_t row_end, void *stream);
 
 /* Device addresses of the two images (bindings 0 and 1 of
  * raytrace.comp.glsl:33-34).  Valid until rt_resize/rt_destroy. */
@@ -162,6 +168,9 @@ int rt_get_extent(rt_handle h, uint32_t *width, uint32_t *height);
  * measured with HIP events on the stream it was launched on; blocks until that
  * kernel has finished.  Negative if nothing has been launched. */
 float rt_last_kernel_ms(rt_handle h);
+/* The same for the trace kernel launched `launches_ago` launches before the most
+ * recent one (0 = most recent; the last 64 launches are kept). */
+float rt_kernel_ms(rt_handle h, uint32_t launches_ago);
 
 /* Text of the last error on this handle (VK_CHECK's message in the reference,
  * src/util/Check.h:8-19).  h may be NULL: then the last rt_create failure. */

@@ -52,9 +52,11 @@ struct rt_tracer {
     uint32_t samples_per_pixel = 4;
     uint32_t max_depth = 12;
 
-    hipEvent_t ev_start = nullptr;
-    hipEvent_t ev_stop = nullptr;
-    bool timed = false;
+    // HIP event pairs around the most recent trace launches (a ring), for rt_kernel_ms
+    static constexpr uint32_t kTimedLaunches = 64;
+    hipEvent_t ev_start[kTimedLaunches] = {};
+    hipEvent_t ev_stop[kTimedLaunches] = {};
+    uint64_t launches = 0;
 
     std::string error;
 };
@@ -303,12 +305,17 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     DeviceScope scope(h->device);
     RT_HIP_TRY(h, scope.status());
 
-    // RayTracer::render, src/rt/RayTracer.cpp:564-603
-    const bool clear_accum = h->reset_accum || first_frame == 0;
-    if (clear_accum) {
+    // RayTracer::render, src/rt/RayTracer.cpp:564-603.  A raised flag clears the whole image once;
+    // frame 0 clears the rows this call renders (the whole image for an unsharded call), so row
+    // bands rendered one after another on one handle do not wipe each other.
+    if (h->reset_accum) {
         const size_t bytes = static_cast<size_t>(h->width) * h->height * sizeof(float4);
         RT_HIP_TRY(h, hipMemsetAsync(h->accum, 0, bytes, stream));
         h->reset_accum = false;
+    } else if (first_frame == 0 && row_end > row_begin) {
+        const size_t offset = static_cast<size_t>(row_begin) * h->width;
+        const size_t bytes = static_cast<size_t>(row_end - row_begin) * h->width * sizeof(float4);
+        RT_HIP_TRY(h, hipMemsetAsync(h->accum + offset, 0, bytes, stream));
     }
 
     rt::TraceArgs args;
@@ -325,10 +332,11 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     args.n_frames = n_frames;
     args.frame_stride = frame_stride;
 
-    RT_HIP_TRY(h, hipEventRecord(h->ev_start, stream));
+    const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);
+    RT_HIP_TRY(h, hipEventRecord(h->ev_start[slot], stream));
     RT_HIP_TRY(h, rt::launch_trace(args, stream));
-    RT_HIP_TRY(h, hipEventRecord(h->ev_stop, stream));
-    h->timed = true;
+    RT_HIP_TRY(h, hipEventRecord(h->ev_stop[slot], stream));
+    ++h->launches;
     return RT_OK;
 }
 
@@ -378,8 +386,10 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
         DeviceScope scope(device_id);
         auto body = [&]() -> int {
             RT_HIP_TRY(h, scope.status());
-            RT_HIP_TRY(h, hipEventCreate(&h->ev_start));
-            RT_HIP_TRY(h, hipEventCreate(&h->ev_stop));
+            for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
+                RT_HIP_TRY(h, hipEventCreate(&h->ev_start[i]));
+                RT_HIP_TRY(h, hipEventCreate(&h->ev_stop[i]));
+            }
             int r = upload_scene(h, nullptr);
             if (r != RT_OK) {
                 return r;
@@ -418,7 +428,6 @@ int rt_resize(rt_handle h, uint32_t width, uint32_t height)
     h->width = width;
     h->height = height;
     h->reset_accum = true; // :228
-    h->timed = false;
     return allocate_images(h);
 }
 
@@ -432,8 +441,10 @@ int rt_destroy(rt_handle h)
         (void)hipDeviceSynchronize(); // vkDeviceWaitIdle, :238
         free_images(h);
         if (h->d_spheres) { (void)hipFree(h->d_spheres); }
-        if (h->ev_start) { (void)hipEventDestroy(h->ev_start); }
-        if (h->ev_stop) { (void)hipEventDestroy(h->ev_stop); }
+        for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
+            if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
+            if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }
+        }
         (void)hipGetLastError();
     }
     delete h;
@@ -587,11 +598,9 @@ int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32
                        static_cast<hipStream_t>(stream));
 }
 
-int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void* stream)
+namespace {
+int resolve_impl(rt_tracer* h, const float4* accum, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, hipStream_t stream)
 {
-    if (h == nullptr) {
-        return RT_ERR_BAD_ARGUMENT;
-    }
     RT_NEED_DEVICE(h);
     if (row_begin > row_end || row_end > h->height) {
         return fail_arg(h, "row range outside the image");
@@ -603,9 +612,31 @@ int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, ui
     if (first + count > 0xFFFFFFFFull) {
         return fail_arg(h, "image too large for the resolve kernel");
     }
-    RT_HIP_TRY(h, rt::launch_resolve(h->accum, h->output, static_cast<uint32_t>(first), static_cast<uint32_t>(count),
-                                     static_cast<float>(sample_count), static_cast<hipStream_t>(stream)));
+    RT_HIP_TRY(h, rt::launch_resolve(accum, h->output, static_cast<uint32_t>(first), static_cast<uint32_t>(count),
+                                     static_cast<float>(sample_count), stream));
     return RT_OK;
+}
+} // namespace
+
+int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    return resolve_impl(h, h->accum, sample_count, row_begin, row_end, static_cast<hipStream_t>(stream));
+}
+
+int rt_resolve_output_from(rt_handle h, const void* accum_device, uint32_t sample_count, uint32_t row_begin,
+                           uint32_t row_end, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (accum_device == nullptr) {
+        return fail_arg(h, "accum_device is NULL");
+    }
+    return resolve_impl(h, static_cast<const float4*>(accum_device), sample_count, row_begin, row_end,
+                        static_cast<hipStream_t>(stream));
 }
 
 void* rt_accum_device_ptr(rt_handle h) { return h ? h->accum : nullptr; }
@@ -717,22 +748,28 @@ int rt_get_extent(rt_handle h, uint32_t* width, uint32_t* height)
     return RT_OK;
 }
 
-float rt_last_kernel_ms(rt_handle h)
+float rt_kernel_ms(rt_handle h, uint32_t launches_ago)
 {
-    if (h == nullptr || !h->timed || h->device < 0) {
+    if (h == nullptr || h->device < 0 || launches_ago >= h->launches || launches_ago >= rt_tracer::kTimedLaunches) {
         return -1.0f;
     }
+    const uint32_t slot = static_cast<uint32_t>((h->launches - 1 - launches_ago) % rt_tracer::kTimedLaunches);
     DeviceScope scope(h->device);
-    if (hipEventSynchronize(h->ev_stop) != hipSuccess) {
+    if (hipEventSynchronize(h->ev_stop[slot]) != hipSuccess) {
         (void)hipGetLastError();
         return -1.0f;
     }
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, h->ev_start, h->ev_stop) != hipSuccess) {
+    if (hipEventElapsedTime(&ms, h->ev_start[slot], h->ev_stop[slot]) != hipSuccess) {
         (void)hipGetLastError();
         return -1.0f;
     }
     return ms;
+}
+
+float rt_last_kernel_ms(rt_handle h)
+{
+    return rt_kernel_ms(h, 0);
 }
 
 const char* rt_last_error(rt_handle h)

@@ -65,6 +65,7 @@ ABI = {
     "rt_render_frames": (ctypes.c_int, [_H, _U32, _U32, _STREAM]),
     "rt_render_shard": (ctypes.c_int, [_H, _U32, _U32, _U32, _U32, _U32, ctypes.c_int, _STREAM]),
     "rt_resolve_output": (ctypes.c_int, [_H, _U32, _U32, _U32, _STREAM]),
+    "rt_resolve_output_from": (ctypes.c_int, [_H, ctypes.c_void_p, _U32, _U32, _U32, _STREAM]),
     "rt_accum_device_ptr": (ctypes.c_void_p, [_H]),
     "rt_output_device_ptr": (ctypes.c_void_p, [_H]),
     "rt_read_accum": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_size_t, _STREAM]),
@@ -75,6 +76,7 @@ ABI = {
     "rt_synchronize": (ctypes.c_int, [_H, _STREAM]),
     "rt_get_extent": (ctypes.c_int, [_H, ctypes.POINTER(_U32), ctypes.POINTER(_U32)]),
     "rt_last_kernel_ms": (ctypes.c_float, [_H]),
+    "rt_kernel_ms": (ctypes.c_float, [_H, _U32]),
     "rt_last_error": (ctypes.c_char_p, [_H]),
     "rt_probe_hit_sphere": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(GPUSphere), ctypes.c_void_p, _U32,
                                            ctypes.c_void_p, ctypes.c_void_p]),
@@ -217,6 +219,12 @@ class RayTracer:
             row_end = self.extent[1]
         self._check(self._lib.rt_resolve_output(self._h, int(sample_count), int(row_begin), int(row_end), self._stream))
 
+    def resolve_output_from(self, accum_device_ptr, sample_count, row_begin=0, row_end=None):
+        if row_end is None:
+            row_end = self.extent[1]
+        self._check(self._lib.rt_resolve_output_from(self._h, ctypes.c_void_p(accum_device_ptr), int(sample_count),
+                                                     int(row_begin), int(row_end), self._stream))
+
     @property
     def extent(self):
         w, h = _U32(), _U32()
@@ -261,6 +269,10 @@ class RayTracer:
 
     def last_kernel_ms(self):
         return float(self._lib.rt_last_kernel_ms(self._h))
+
+    def kernel_ms(self, launches_ago=0):
+        """GPU time of one of the last 64 trace launches (HIP events on the launch stream)."""
+        return float(self._lib.rt_kernel_ms(self._h, int(launches_ago)))
 
     def __del__(self):
         try:

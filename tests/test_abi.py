@@ -122,3 +122,23 @@ def test_scene_generators(pkg, oracle):
     b = pkg.synthetic_scene(300)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.shape == (300, 12)
     assert set(np.unique(a[:, 8])) <= {0.0, 1.0, 2.0}
+
+
+def test_cpp_mirror_of_reference_class(pkg, golden_dir, tmp_path):
+    """The header-only C++ RayTracer (same method names as src/rt/RayTracer.h:40-51) links against the
+    C ABI and produces the reference's uniform block; render on a device-less handle throws."""
+    import subprocess
+    exe = str(tmp_path / "cpp_mirror_check")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp_mirror_check.cpp"),
+                           "-o", exe, "-L" + libdir, "-lrt_mi355x", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    cases = json.load(open(os.path.join(golden_dir, "host_params.json")))
+    want = cases["default_1920x1080_ap0.05"]["params"]
+    got = lines[0].split()
+    assert got[:28] == want[:28] and got[32:] == want[32:]
+    assert got[28:32] == ["00000000", "00000004", "0000000c", "00000005"]
+    assert "RT_DEVICE_NONE" in lines[1]

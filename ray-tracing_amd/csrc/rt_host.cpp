@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -39,6 +40,9 @@ struct rt_tracer {
     uint32_t d_sphere_capacity = 0;
     uint32_t* rng_state = nullptr;    // test hook
     bool rng_capture = false;
+    float4* partial = nullptr;        // per-frame sums of a multi-frame launch: [frames][height*width]
+    size_t partial_bytes = 0;
+    uint32_t* stats = nullptr;        // diagnostic builds only
 
     bool reset_accum = true;          // mResetAccum
     std::vector<rt_gpu_sphere> spheres; // mSpheres
@@ -222,6 +226,7 @@ void free_images(rt_tracer* h)
     if (h->accum) { (void)hipFree(h->accum); h->accum = nullptr; }
     if (h->output) { (void)hipFree(h->output); h->output = nullptr; }
     if (h->rng_state) { (void)hipFree(h->rng_state); h->rng_state = nullptr; }
+    if (h->partial) { (void)hipFree(h->partial); h->partial = nullptr; h->partial_bytes = 0; }
 }
 
 // RayTracer::createAccumulationImage, src/rt/RayTracer.cpp:498-527 (+ the output image
@@ -318,25 +323,78 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         RT_HIP_TRY(h, hipMemsetAsync(h->accum + offset, 0, bytes, stream));
     }
 
-    rt::TraceArgs args;
-    update_params(*h, first_frame, args.params);
-    args.accum = h->accum;
-    args.output = write_output ? h->output : nullptr;
-    args.spheres = h->d_spheres;
-    args.rng_out = h->rng_capture ? h->rng_state : nullptr;
-    args.width = h->width;
-    args.height = h->height;
-    args.row_begin = row_begin;
-    args.row_end = row_end;
-    args.first_frame = first_frame;
-    args.n_frames = n_frames;
-    args.frame_stride = frame_stride;
+    // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
+    // accumulator in frame order afterwards; the frames of one call are split into groups so that
+    // this image stays within a budget (4 GiB unless RT_PARTIAL_BYTES says otherwise).
+    const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
+    const size_t frame_bytes = image_pixels * sizeof(float4);
+    uint32_t group = n_frames;
+    if (n_frames > 1) {
+        size_t budget = static_cast<size_t>(4) << 30;
+        if (const char* e = std::getenv("RT_PARTIAL_BYTES")) {
+            budget = static_cast<size_t>(std::strtoull(e, nullptr, 10));
+        }
+        const size_t fit = std::max<size_t>(2, budget / frame_bytes);
+        group = static_cast<uint32_t>(std::min<size_t>(n_frames, fit));
+        const size_t need = static_cast<size_t>(group) * frame_bytes;
+        if (need > h->partial_bytes) {
+            RT_HIP_TRY(h, hipStreamSynchronize(stream));
+            if (h->partial) {
+                (void)hipFree(h->partial);
+                h->partial = nullptr;
+                h->partial_bytes = 0;
+            }
+            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->partial), need));
+            h->partial_bytes = need;
+        }
+    }
+    uint32_t frames_per_unit = 16;
+    if (const char* e = std::getenv("RT_FRAMES_PER_UNIT")) {
+        frames_per_unit = static_cast<uint32_t>(std::max(1, std::atoi(e)));
+    }
 
-    const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);
-    RT_HIP_TRY(h, hipEventRecord(h->ev_start[slot], stream));
-    RT_HIP_TRY(h, rt::launch_trace(args, stream));
-    RT_HIP_TRY(h, hipEventRecord(h->ev_stop[slot], stream));
-    ++h->launches;
+    for (uint32_t done = 0; done < n_frames; done += group) {
+        const uint32_t count = std::min(group, n_frames - done);
+        const uint32_t first = first_frame + done * frame_stride;
+        const bool last_group = done + count == n_frames;
+        rt::TraceArgs args;
+        update_params(*h, first, args.params);
+        args.accum = h->accum;
+        args.output = (write_output && count == 1) ? h->output : nullptr;
+        args.spheres = h->d_spheres;
+        args.rng_out = (h->rng_capture && last_group) ? h->rng_state : nullptr;
+        args.partial = count > 1 ? h->partial : nullptr;
+        args.stats = h->stats;
+        args.width = h->width;
+        args.height = h->height;
+        args.row_begin = row_begin;
+        args.row_end = row_end;
+        args.first_frame = first;
+        args.n_frames = count;
+        args.frame_stride = frame_stride;
+        args.frames_per_unit = frames_per_unit;
+        args.tiles_x = args.n_tiles = args.n_chunks = 0;
+
+        const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);
+        RT_HIP_TRY(h, hipEventRecord(h->ev_start[slot], stream));
+        RT_HIP_TRY(h, rt::launch_trace(args, stream));
+        RT_HIP_TRY(h, hipEventRecord(h->ev_stop[slot], stream));
+        ++h->launches;
+
+        if (count > 1) {
+            const uint32_t last_frame = first + (count - 1) * frame_stride;
+            const size_t first_texel = static_cast<size_t>(row_begin) * h->width;
+            const size_t texels = static_cast<size_t>(row_end - row_begin) * h->width;
+            if (texels > 0xFFFFFFFFull) {
+                return fail_arg(h, "image too large for the fold kernel");
+            }
+            // (frame + 1u) * spp wraps in uint32 before the conversion, raytrace.comp.glsl:337
+            const float sample_count = static_cast<float>((last_frame + 1u) * h->samples_per_pixel);
+            RT_HIP_TRY(h, rt::launch_fold(h->accum, h->partial, (write_output && last_group) ? h->output : nullptr,
+                                          image_pixels, first_texel, static_cast<uint32_t>(texels), count, sample_count,
+                                          stream));
+        }
+    }
     return RT_OK;
 }
 
@@ -771,6 +829,30 @@ float rt_last_kernel_ms(rt_handle h)
 {
     return rt_kernel_ms(h, 0);
 }
+
+#ifdef RT_STATS
+// Diagnostic builds only: per-section (wave executions, active lanes) pairs accumulated since the
+// handle was created; out receives 2 * rt_debug_stats_sections() 64-bit counters.
+int rt_debug_stats_sections(void) { return rt::stats_section_count(); }
+int rt_debug_read_stats(rt_handle h, unsigned long long* out, int reset)
+{
+    if (h == nullptr || h->device < 0 || out == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    DeviceScope scope(h->device);
+    const size_t bytes = sizeof(unsigned long long) * 2 * rt::stats_section_count();
+    if (h->stats == nullptr) {
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->stats), bytes));
+        RT_HIP_TRY(h, hipMemset(h->stats, 0, bytes));
+    }
+    RT_HIP_TRY(h, hipDeviceSynchronize());
+    RT_HIP_TRY(h, hipMemcpy(out, h->stats, bytes, hipMemcpyDeviceToHost));
+    if (reset) {
+        RT_HIP_TRY(h, hipMemset(h->stats, 0, bytes));
+    }
+    return RT_OK;
+}
+#endif
 
 const char* rt_last_error(rt_handle h)
 {

@@ -1,18 +1,29 @@
 // HIP kernels of the sphere path tracer for gfx950 (MI355X).
 //
 // rt_trace_kernel is the counterpart of main() in shaders/raytrace.comp.glsl:298-343,
-// restructured for 64-wide wavefronts:
-//   * one lane owns one pixel for the whole launch and walks its frames and the
-//     samples of each frame in order, so the per-(pixel,frame) random stream of
-//     :310-331 is consumed exactly as the shader consumes it;
-//   * the bounce loop (:242-293) and the sample loop (:315-331) are flattened into
-//     one loop whose iteration is "one ray segment": a lane whose path has ended
-//     starts its next camera ray in the same iteration instead of idling until the
-//     longest path of the wave has finished;
-//   * the sphere list is staged once per workgroup in LDS as (centre, radius^2)
-//     float4 records that every lane reads at the same address (broadcast), and the
-//     material records are fetched only for the winning sphere;
-//   * the accumulator texel is read once and written once per launch as one float4.
+// restructured for 64-wide wavefronts.
+//
+// Work decomposition.  The unit of independent work is an ITEM = one (pixel, frame) pair: its
+// `spp` samples share one random stream (:310-331) whose draw count per sample is data dependent,
+// so they stay on one lane, in order.  A wave owns a UNIT = one 8x8 pixel tile x a chunk of up to
+// `frames_per_unit` frames, i.e. a pool of up to 64 x frames_per_unit items.  Lanes pull items from
+// the pool with a ballot/prefix count (no atomics, no LDS): a lane that finishes its item takes the
+// next one, so all 64 lanes stay busy until the pool drains, whatever the path lengths were.
+//
+// The loop body is one RAY SEGMENT per lane: the bounce loop (:242-293) and the sample loop
+// (:315-331) are flattened, and a lane whose path ended generates its next camera ray in the same
+// iteration.  The five normalize() calls of the shader (camera :328, lambert :72 and :159, metal
+// :201, dielectric :215, sky :263) are merged into two per iteration with per-lane selected
+// operands, and the rejection samplers of lambert (:157) and metal (:204) share one loop, so the
+// expensive correctly rounded sqrt/divide sequences run with most lanes active.
+//
+// Accumulation.  A launch of one frame adds the frame's sum to the accumulator texel directly
+// (:333-335).  A launch of several frames stores each item's sum in a per-frame image
+// (partial[frame][pixel], HBM) and rt_fold_kernel then adds them to the texel in frame order, which
+// reproduces the float additions of consecutive dispatches exactly.
+//
+// The sphere list is staged once per workgroup in LDS as (centre, radius^2) float4 records read at
+// a wave-uniform address (broadcast); material records are fetched only for the winning sphere.
 //
 // Compile with -ffp-contract=off (see rt_device.hpp).
 #include "rt_device.hpp"
@@ -23,7 +34,55 @@ namespace rt {
 namespace {
 
 constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr float kTMin = 0.001f;
+
+// ---- diagnostic section counters -------------------------------------------------------------
+// A diagnostic build (-DRT_STATS) counts, per code section, how often a wave executes it and the
+// number of active lanes.  The shipped library instantiates the kernel with NoStats only.
+enum Section {
+    ST_ITER, ST_ITEM, ST_GEN, ST_DISK_IT, ST_NORM2, ST_ROOT, ST_FAR_ROOT, ST_HIT, ST_RIS, ST_RIS_IT,
+    ST_SKY, ST_LAMBERT, ST_CHECKER, ST_METAL, ST_DIEL, ST_SCHLICK, ST_COUNT
+};
+
+struct NoStats {
+    __device__ __forceinline__ void section(int) {}
+    __device__ __forceinline__ void flush(uint32_t*) {}
+};
+
+struct WaveStats {
+    uint32_t exec[ST_COUNT];
+    uint32_t lanes[ST_COUNT];
+    __device__ __forceinline__ WaveStats()
+    {
+        for (int i = 0; i < ST_COUNT; ++i) {
+            exec[i] = 0;
+            lanes[i] = 0;
+        }
+    }
+    __device__ __forceinline__ void section(int k)
+    {
+        unsigned long long m = __ballot(1);
+        lanes[k] += 1u;
+        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1)) {
+            exec[k] += 1u;
+        }
+    }
+    __device__ __forceinline__ void flush(uint32_t* out)
+    {
+        if (out == nullptr) {
+            return;
+        }
+        for (int i = 0; i < ST_COUNT; ++i) {
+            if (exec[i]) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * i, (unsigned long long)exec[i]);
+            }
+            if (lanes[i]) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * i + 1, (unsigned long long)lanes[i]);
+            }
+        }
+    }
+};
 
 // Copies the scene into LDS: geometry always, material records when they fit.
 template <bool MAT_IN_LDS>
@@ -43,7 +102,13 @@ __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ sp
     __syncthreads();
 }
 
-template <bool MAT_IN_LDS>
+// Number of set bits of a wave mask below this lane.
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool MAT_IN_LDS, class Stats>
 __global__ __launch_bounds__(kBlockThreads) void rt_trace_kernel(TraceArgs A)
 {
     extern __shared__ float4 lds[];
@@ -53,23 +118,31 @@ __global__ __launch_bounds__(kBlockThreads) void rt_trace_kernel(TraceArgs A)
     float4* mat1 = lds + 2 * sphere_count;
     stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1);
 
-    // One wave = one 8x8 pixel tile (the reference's workgroup shape, :5).
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = blockIdx.x * (kBlockThreads / 64) + (threadIdx.x >> 6);
-    const uint32_t tiles_x = (A.width + 7u) >> 3;
-    const uint32_t tile_y = tile / tiles_x;
-    const uint32_t tile_x = tile - tile_y * tiles_x;
-    const uint32_t px = tile_x * 8u + (lane & 7u);
-    const uint32_t py = A.row_begin + tile_y * 8u + (lane >> 3);
+    Stats st;
 
-    // :302-305 bounds check (plus the row band of this shard)
-    if (px >= A.width || py >= A.row_end) {
+    // ---- this wave's unit: (tile, frame chunk), chunk-major ----
+    const uint32_t unit = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (unit >= A.n_tiles * A.n_chunks) {
         return;
     }
+    const uint32_t chunk = unit / A.n_tiles;
+    const uint32_t tile = unit - chunk * A.n_tiles;
+    const uint32_t tile_y = tile / A.tiles_x;
+    const uint32_t tile_x = tile - tile_y * A.tiles_x;
+    const uint32_t x0 = tile_x * 8u;
+    const uint32_t y0 = A.row_begin + tile_y * 8u;
+    const uint32_t tile_w = min(8u, A.width - x0);    // :302-305 bounds (ragged right/bottom edges)
+    const uint32_t tile_h = min(8u, A.row_end - y0);
+    const uint32_t tile_pixels = tile_w * tile_h;
+    const uint32_t rel_begin = chunk * A.frames_per_unit;
+    const uint32_t rel_count = min(A.frames_per_unit, A.n_frames - rel_begin);
+    const uint32_t n_items = tile_pixels * rel_count;
+    uint32_t next_item = 0; // wave-uniform pool cursor
 
     const uint32_t spp_raw = A.params.frame_sample_depth_count[1];
     const uint32_t spp = spp_raw > 1u ? spp_raw : 1u; // :308
     const uint32_t max_depth = A.params.frame_sample_depth_count[2];
+    const size_t image_pixels = (size_t)A.width * A.height;
 
     const f3 origin = mk(A.params.origin_lens[0], A.params.origin_lens[1], A.params.origin_lens[2]);
     const float lens_radius = A.params.origin_lens[3];
@@ -80,154 +153,275 @@ __global__ __launch_bounds__(kBlockThreads) void rt_trace_kernel(TraceArgs A)
     const f3 cam_v = mk(A.params.v[0], A.params.v[1], A.params.v[2]);
     const float inv_w = A.params.inv_resolution[0];
     const float inv_h = A.params.inv_resolution[1];
-    const float fpx = (float)(int32_t)px;
-    // float(params.resolution.y - 1u - pixel.y), :320
-    const float fpy_flipped = (A.params.resolution[1] - 1.0f) - (float)(int32_t)py;
+    const float res_y_minus_1 = A.params.resolution[1] - 1.0f; // float(params.resolution.y - 1u ...), :320
 
-    const size_t texel = (size_t)py * A.width + px;
-    const float4 prev = A.accum[texel]; // :333
-    f3 total = mk(prev.x, prev.y, prev.z);
-
-    uint32_t frame = A.first_frame;
-    uint32_t frames_left = A.n_frames;
-    uint32_t samples_left = spp;
-    uint32_t rng = hash3(px, py, frame); // :310-311
-    f3 frame_sum = mk(0.0f, 0.0f, 0.0f); // `accum` of :313
-    bool need_ray = true;
+    // ---- per-lane state ----
+    bool has_item = false;
+    bool ended = true;        // the current path is over: start the next sample (or the next item)
+    bool pending_norm = false; // rd still has to be normalized (camera ray :328, lambert :159)
+    uint32_t samples_left = 0;
+    uint32_t rel = 0;         // frame of the current item, relative to first_frame
+    uint32_t rng = 0;
     uint32_t depth = 0;
+    size_t texel = 0;
+    float fpx = 0.0f, fpy_flipped = 0.0f;
+    f3 frame_sum = mk(0.0f, 0.0f, 0.0f); // `accum` of :313
     f3 ro = origin, rd = origin;
     f3 throughput = mk(1.0f, 1.0f, 1.0f);
 
-    while (frames_left != 0u) {
-        if (need_ray) {
-            if (samples_left == 0u) {
-                // end of one dispatch for this pixel: :333-335
-                total = total + frame_sum;
-                frame_sum = mk(0.0f, 0.0f, 0.0f);
-                --frames_left;
-                if (frames_left == 0u) {
-                    break;
+    for (;;) {
+        st.section(ST_ITER);
+        // ------------------------------------------------------------------ item bookkeeping
+        const bool need_item = ended && samples_left == 0u;
+        if (need_item && has_item) {
+            // one dispatch's worth of this pixel is done: :333-335
+            if (A.partial != nullptr) {
+                A.partial[(size_t)rel * image_pixels + texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
+            } else {
+                const float4 prev = A.accum[texel];
+                const f3 total = mk(prev.x, prev.y, prev.z) + frame_sum;
+                A.accum[texel] = make_float4(total.x, total.y, total.z, 1.0f);
+                if (A.output != nullptr) {
+                    // :337 (frame + 1u) * spp wraps in uint32 before the conversion
+                    const uint32_t frame = A.first_frame + rel * A.frame_stride;
+                    A.output[texel] = tonemap_rgba8(total, (float)((frame + 1u) * spp_raw));
                 }
-                frame += A.frame_stride;
-                rng = hash3(px, py, frame);
-                samples_left = spp;
             }
+            if (A.rng_out != nullptr && rel + 1u == A.n_frames) {
+                A.rng_out[texel] = rng;
+            }
+        }
+        // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
+        const unsigned long long want = __ballot(need_item);
+        const uint32_t my_item = next_item + lane_prefix(want);
+        next_item += (uint32_t)__popcll(want);
+        if (need_item) {
+            if (my_item >= n_items) {
+                break; // pool drained: this lane is done
+            }
+            st.section(ST_ITEM);
+            uint32_t frame_in_chunk, pix;
+            if (tile_pixels == 64u) {
+                frame_in_chunk = my_item >> 6;
+                pix = my_item & 63u;
+            } else {
+                frame_in_chunk = my_item / tile_pixels;
+                pix = my_item - frame_in_chunk * tile_pixels;
+            }
+            uint32_t ly, lx;
+            if (tile_w == 8u) {
+                ly = pix >> 3;
+                lx = pix & 7u;
+            } else {
+                ly = pix / tile_w;
+                lx = pix - ly * tile_w;
+            }
+            const uint32_t px = x0 + lx;
+            const uint32_t py = y0 + ly;
+            rel = rel_begin + frame_in_chunk;
+            texel = (size_t)py * A.width + px;
+            fpx = (float)(int32_t)px;
+            fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
+            rng = hash3(px, py, A.first_frame + rel * A.frame_stride); // :310-311
+            samples_left = spp;
+            frame_sum = mk(0.0f, 0.0f, 0.0f);
+            has_item = true;
+        }
+
+        // ------------------------------------------------------------------ camera ray, :317-328
+        if (ended) {
+            st.section(ST_GEN);
             --samples_left;
-            // camera ray, :317-328
             float u_coord = (fpx + rnd(rng)) * inv_w;
             float v_coord = (fpy_flipped + rnd(rng)) * inv_h;
             float dx, dy;
-            random_in_unit_disk(rng, dx, dy);
+            do {
+                st.section(ST_DISK_IT);
+                float a = rnd(rng);
+                float b = rnd(rng);
+                dx = a * 2.0f - 1.0f;
+                dy = b * 2.0f - 1.0f;
+            } while ((dx * dx + dy * dy) >= 1.0f); // :75-86
             float rdx = lens_radius * dx;
             float rdy = lens_radius * dy;
             f3 offset = cam_u * rdx + cam_v * rdy;
-            f3 dir = lower_left + horizontal * u_coord + vertical * v_coord - origin - offset;
+            rd = lower_left + horizontal * u_coord + vertical * v_coord - origin - offset;
             ro = origin + offset;
-            rd = normalize(dir);
+            pending_norm = true;
             throughput = mk(1.0f, 1.0f, 1.0f);
             depth = 0u;
-            need_ray = false;
+            ended = false;
         }
 
-        // closest hit over all spheres, :244-259
+        // ------------------------------------------------------------------ merged normalize #2
+        if (pending_norm) {
+            st.section(ST_NORM2);
+            rd = normalize(rd); // :328 (camera) or :159 (lambert)
+            pending_norm = false;
+        }
+
+        // ------------------------------------------------------------------ closest hit, :244-259
         float closest = 1e20f;
         int best = -1;
-        const float a = dot(rd, rd);
-        for (uint32_t i = 0; i < sphere_count; ++i) {
-            float root;
-            if (sphere_root(geom[i], ro, rd, a, kTMin, closest, root)) {
-                closest = root;
-                best = (int)i;
+        {
+            const float a = dot(rd, rd);
+            for (uint32_t i = 0; i < sphere_count; ++i) {
+                const float4 g = geom[i];
+                f3 oc = ro - mk(g.x, g.y, g.z);
+                float half_b = dot(oc, rd);
+                float c = dot(oc, oc) - g.w;
+                float discriminant = half_b * half_b - a * c;
+                if (!(discriminant < 0.0f)) { // :117
+                    st.section(ST_ROOT);
+                    float sqrt_disc = sqrtf(discriminant);
+                    float root = (-half_b - sqrt_disc) / a;
+                    bool ok = true;
+                    if (root < kTMin || root > closest) { // :125
+                        st.section(ST_FAR_ROOT);
+                        root = (-half_b + sqrt_disc) / a;
+                        ok = !(root < kTMin || root > closest); // :129
+                    }
+                    if (ok) {
+                        closest = root;
+                        best = (int)i;
+                    }
+                }
             }
         }
+        const bool hit = best >= 0;
 
-        if (best < 0) {
+        // ------------------------------------------------------------------ winner's record, :135-149
+        f3 p = ro, n = ro, albedo = ro;
+        bool front = false;
+        uint32_t mat = 3u;
+        float fuzz = 0.0f, ref_idx = 1.0f, flags = 0.0f;
+        if (hit) {
+            st.section(ST_HIT);
+            const float4 g = geom[best];
+            float4 m0, m1;
+            if (MAT_IN_LDS) {
+                m0 = mat0[best];
+                m1 = mat1[best];
+            } else {
+                const float4* src = reinterpret_cast<const float4*>(A.spheres + best);
+                const float4 cr = src[0];
+                const float4 al = src[1];
+                m0 = make_float4(al.x, al.y, al.z, cr.w);
+                m1 = src[2];
+            }
+            hit_finish(mk(g.x, g.y, g.z), m0.w, ro, rd, closest, p, n, front);
+            mat = (uint32_t)(m1.x + 0.5f); // :145
+            albedo = mk(m0.x, m0.y, m0.z);
+            fuzz = m1.y;
+            ref_idx = m1.z;
+            flags = m1.w;
+        }
+        const bool is_lambert = hit && mat == 0u;
+        const bool is_metal = hit && mat == 1u;
+
+        // ------------------------------------------------------------------ shared rejection sampler
+        f3 ris = ro;
+        if (is_lambert || is_metal) {
+            st.section(ST_RIS);
+            do {
+                st.section(ST_RIS_IT);
+                float a = rnd(rng);
+                float b = rnd(rng);
+                float c = rnd(rng);
+                ris = mk(a * 2.0f - 1.0f, b * 2.0f - 1.0f, c * 2.0f - 1.0f);
+            } while (dot(ris, ris) >= 1.0f); // :57-68
+        }
+
+        // ------------------------------------------------------------------ merged normalize #1
+        // lambert: randomUnitVector = normalize(ris), :72.  everything else: normalize(ray.d),
+        // :201 (metal), :215 (dielectric), :263 (sky).
+        const f3 unit = normalize(is_lambert ? ris : rd);
+
+        bool scattered = true;
+        if (!hit) {
             // sky, :261-269
-            f3 unit_dir = normalize(rd);
-            float t = 0.5f * (unit_dir.y + 1.0f);
+            st.section(ST_SKY);
+            float t = 0.5f * (unit.y + 1.0f);
             float omt = 1.0f - t;
             f3 sky = mk(omt + 0.5f * t, omt + 0.7f * t, omt + 1.0f * t);
             f3 radiance = mk(0.0f, 0.0f, 0.0f) + throughput * sky;
             frame_sum = frame_sum + radiance; // :330
-            need_ray = true;
-            continue;
-        }
-
-        // winner's record, :135-149
-        float4 g = geom[best];
-        float4 m0, m1;
-        if (MAT_IN_LDS) {
-            m0 = mat0[best];
-            m1 = mat1[best];
-        } else {
-            const float4* src = reinterpret_cast<const float4*>(A.spheres + best);
-            float4 cr = src[0];
-            float4 al = src[1];
-            m0 = make_float4(al.x, al.y, al.z, cr.w);
-            m1 = src[2];
-        }
-        f3 p, n;
-        bool front;
-        hit_finish(mk(g.x, g.y, g.z), m0.w, ro, rd, closest, p, n, front);
-        const uint32_t mat = (uint32_t)(m1.x + 0.5f);
-        f3 albedo = mk(m0.x, m0.y, m0.z);
-        bool scattered = true;
-
-        if (mat == 0u) {
+            ended = true;
+        } else if (is_lambert) {
             // scatterLambert, :155-174
-            f3 ruv = normalize(random_in_unit_sphere(rng));
-            f3 target = p + n + ruv;
+            st.section(ST_LAMBERT);
+            f3 target = p + n + unit;
             ro = p + n * 0.001f;
-            rd = normalize(target - p);
-            if (m1.w > 0.5f) {
+            rd = target - p;
+            pending_norm = true; // normalize(target - p) at the top of the next iteration
+            if (flags > 0.5f) {
+                st.section(ST_CHECKER);
                 float checker_index = floorf(p.x) + floorf(p.z);
                 float checker = checker_index - 2.0f * floorf(checker_index / 2.0f);
                 float tone = (checker < 1.0f) ? 0.05f : 0.95f;
                 albedo = albedo * tone;
             }
             throughput = throughput * albedo;
-        } else if (mat == 1u) {
+        } else if (is_metal) {
             // scatterMetal, :199-208
-            f3 reflected = reflect(normalize(rd), n);
+            st.section(ST_METAL);
+            f3 reflected = reflect(unit, n);
             ro = p + n * 0.001f;
-            rd = reflected + random_in_unit_sphere(rng) * m1.y;
+            rd = reflected + ris * fuzz;
             throughput = throughput * albedo;
             scattered = dot(rd, n) > 0.0f;
         } else {
             // scatterDielectric, :210-234
+            st.section(ST_DIEL);
             throughput = throughput * mk(1.0f, 1.0f, 1.0f);
-            float eta_ratio = front ? (1.0f / m1.z) : m1.z;
-            f3 unit_dir = normalize(rd);
-            float cos_theta = glsl_min(dot(-unit_dir, n), 1.0f);
+            float eta_ratio = front ? (1.0f / ref_idx) : ref_idx;
+            float cos_theta = glsl_min(dot(-unit, n), 1.0f);
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
             bool do_reflect = eta_ratio * sin_theta > 1.0f;
             if (!do_reflect) {
                 // `||` short-circuits: the draw happens only on this side
+                st.section(ST_SCHLICK);
                 float sch = schlick(cos_theta, eta_ratio);
                 do_reflect = sch > rnd(rng);
             }
             f3 direction;
-            if (do_reflect || !refract_vec(unit_dir, n, eta_ratio, direction)) {
-                direction = reflect(unit_dir, n);
+            if (do_reflect || !refract_vec(unit, n, eta_ratio, direction)) {
+                direction = reflect(unit, n);
             }
             ro = p + direction * 0.001f;
             rd = direction;
         }
-
-        ++depth;
-        if (!scattered || depth >= max_depth) {
-            need_ray = true; // :287-290 break, or the bounce budget of :242 is spent
+        if (hit) {
+            ++depth;
+            if (!scattered || depth >= max_depth) {
+                ended = true; // :287-290 break, or the bounce budget of :242 is spent
+            }
         }
     }
+    st.flush(A.stats);
+}
 
-    A.accum[texel] = make_float4(total.x, total.y, total.z, 1.0f); // :335
-    if (A.rng_out != nullptr) {
-        A.rng_out[texel] = rng;
+// Adds the per-frame sums of a multi-frame launch to the accumulator in frame order (:333-335 of
+// consecutive dispatches) and, if asked, runs the display tail of the last frame (:337-342).
+__global__ __launch_bounds__(kBlockThreads) void rt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ partial,
+                                                                uint32_t* __restrict__ output, size_t image_pixels,
+                                                                size_t first, uint32_t count, uint32_t n_frames,
+                                                                float sample_count)
+{
+    uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= count) {
+        return;
     }
-    if (A.output != nullptr) {
-        // :337 (frame + 1u) * spp wraps in uint32 before the conversion
-        float sample_count = (float)((frame + 1u) * spp_raw);
-        A.output[texel] = tonemap_rgba8(total, sample_count);
+    const size_t texel = first + i;
+    const float4 prev = accum[texel];
+    f3 total = mk(prev.x, prev.y, prev.z);
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const float4 s = partial[(size_t)f * image_pixels + texel];
+        total = total + mk(s.x, s.y, s.z);
+    }
+    accum[texel] = make_float4(total.x, total.y, total.z, 1.0f);
+    if (output != nullptr) {
+        output[texel] = tonemap_rgba8(total, sample_count);
     }
 }
 
@@ -305,26 +499,61 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
     return (size_t)sphere_count * (full ? 48u : 16u);
 }
 
-hipError_t launch_trace(const TraceArgs& args, hipStream_t stream)
+hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
 {
+    TraceArgs args = args_in;
     const uint32_t rows = args.row_end - args.row_begin;
-    const uint32_t tiles_x = (args.width + 7u) / 8u;
-    const uint32_t tiles_y = (rows + 7u) / 8u;
-    const uint64_t tiles = (uint64_t)tiles_x * tiles_y;
-    const uint32_t waves_per_block = kBlockThreads / 64;
-    const uint64_t blocks = (tiles + waves_per_block - 1) / waves_per_block;
-    if (blocks == 0 || args.n_frames == 0) {
+    if (rows == 0 || args.n_frames == 0) {
         return hipSuccess;
+    }
+    args.tiles_x = (args.width + 7u) / 8u;
+    const uint32_t tiles_y = (rows + 7u) / 8u;
+    const uint64_t tiles = (uint64_t)args.tiles_x * tiles_y;
+    if (args.frames_per_unit == 0) {
+        args.frames_per_unit = 1;
+    }
+    args.frames_per_unit = args.frames_per_unit > 64u ? 64u : args.frames_per_unit;
+    args.n_chunks = (args.n_frames + args.frames_per_unit - 1) / args.frames_per_unit;
+    const uint64_t units = tiles * args.n_chunks;
+    const uint64_t blocks = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (units > 0xFFFFFFFFull || blocks > 0x7FFFFFFFull) {
+        return hipErrorInvalidValue;
+    }
+    args.n_tiles = (uint32_t)tiles;
+    if (args.n_frames > 1 && args.partial == nullptr) {
+        return hipErrorInvalidValue; // several frames need the per-frame sum image
     }
     bool full = false;
     const size_t lds = trace_lds_bytes(args.params.frame_sample_depth_count[3], &full);
+#ifdef RT_STATS
     if (full) {
-        hipLaunchKernelGGL(rt_trace_kernel<true>, dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
+        hipLaunchKernelGGL((rt_trace_kernel<true, WaveStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
     } else {
-        hipLaunchKernelGGL(rt_trace_kernel<false>, dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
+        hipLaunchKernelGGL((rt_trace_kernel<false, WaveStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
     }
+#else
+    if (full) {
+        hipLaunchKernelGGL((rt_trace_kernel<true, NoStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
+    } else {
+        hipLaunchKernelGGL((rt_trace_kernel<false, NoStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
+    }
+#endif
     return hipGetLastError();
 }
+
+hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, size_t image_pixels, size_t first,
+                       uint32_t count, uint32_t n_frames, float sample_count, hipStream_t stream)
+{
+    if (count == 0 || n_frames == 0) {
+        return hipSuccess;
+    }
+    const uint32_t blocks = (count + kBlockThreads - 1) / kBlockThreads;
+    hipLaunchKernelGGL(rt_fold_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, accum, partial, output, image_pixels,
+                       first, count, n_frames, sample_count);
+    return hipGetLastError();
+}
+
+int stats_section_count() { return ST_COUNT; }
 
 hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first, uint32_t count, float sample_count, hipStream_t stream)
 {

@@ -21,10 +21,12 @@ constexpr uint32_t kMaxSpheres = 4096;
 // first_frame/frame_stride.
 struct TraceArgs {
     rt_gpu_params params;
-    float4* accum;               // binding 0, float4 per pixel, pitch = width
-    uint32_t* output;            // binding 1, rgba8 per pixel, or nullptr to skip the display tail
+    float4* accum;                // binding 0, float4 per pixel, pitch = width
+    uint32_t* output;             // binding 1, rgba8 per pixel, or nullptr to skip the display tail
     const rt_gpu_sphere* spheres; // binding 2
-    uint32_t* rng_out;           // optional per-pixel final RNG state
+    uint32_t* rng_out;            // optional per-pixel final RNG state
+    float4* partial;              // [n_frames][height*width] per-frame sums; required when n_frames > 1
+    uint32_t* stats;              // diagnostic builds only
     uint32_t width;
     uint32_t height;
     uint32_t row_begin;
@@ -32,10 +34,18 @@ struct TraceArgs {
     uint32_t first_frame;
     uint32_t n_frames;
     uint32_t frame_stride;
+    uint32_t frames_per_unit;     // frames of one tile a wave pools together (1..64)
+    // filled in by launch_trace
+    uint32_t tiles_x;
+    uint32_t n_tiles;
+    uint32_t n_chunks;
 };
 
 size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds);
 hipError_t launch_trace(const TraceArgs& args, hipStream_t stream);
+hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, size_t image_pixels, size_t first,
+                       uint32_t count, uint32_t n_frames, float sample_count, hipStream_t stream);
+int stats_section_count();
 hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first, uint32_t count,
                           float sample_count, hipStream_t stream);
 hipError_t launch_probe_hit(const rt_gpu_sphere* spheres, const float* rays, uint32_t n, float* out,

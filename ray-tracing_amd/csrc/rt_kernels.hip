@@ -33,6 +33,14 @@ namespace rt {
 
 namespace {
 
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 1
+#endif
+#ifdef RT_NUM_SGPR
+#define RT_SGPR_ATTR __attribute__((amdgpu_num_sgpr(RT_NUM_SGPR)))
+#else
+#define RT_SGPR_ATTR
+#endif
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr float kTMin = 0.001f;
@@ -109,7 +117,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
 }
 
 template <bool MAT_IN_LDS, class Stats>
-__global__ __launch_bounds__(kBlockThreads) void rt_trace_kernel(TraceArgs A)
+__global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
     extern __shared__ float4 lds[];
     const uint32_t sphere_count = A.params.frame_sample_depth_count[3];

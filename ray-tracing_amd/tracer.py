@@ -92,7 +92,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # RT_MI355X_LIB selects another build of the same library (A/B timing of kernel variants)
+    p = path or os.environ.get("RT_MI355X_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(
             "HIP library %s is missing: build it with `make -C ray-tracing_amd/csrc` "

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Runs the benchmark workload once on the diagnostic build (make -C ray-tracing_amd/csrc stats) and
+prints, per code section of the trace kernel, how often a wave executed it and the mean number of
+active lanes.  Usage (GPU box):  python tools/section_stats.py [frames]
+"""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SECTIONS = ["iter", "item", "gen", "disk_it", "norm2", "root", "far_root", "hit", "ris", "ris_it",
+            "sky", "lambert", "checker", "metal", "diel", "schlick"]
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    import rtamd_loader
+    pkg = rtamd_loader.load()
+    from raytracing_amd import tracer as tr
+    path = os.path.join(ROOT, "ray-tracing_amd", "librt_mi355x_stats.so")
+    lib = tr.load_library(path)
+    tr._lib = lib  # the RayTracer mirror binds to this build
+    lib.rt_debug_stats_sections.restype = ctypes.c_int
+    lib.rt_debug_read_stats.restype = ctypes.c_int
+    lib.rt_debug_read_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    n = lib.rt_debug_stats_sections()
+    assert n == len(SECTIONS), (n, len(SECTIONS))
+    t = pkg.RayTracer().create(1920, 1080, device_id=0)
+    t.set_samples_per_pixel(16)
+    t.set_max_depth(8)
+    t.set_aperture(0.0)
+    buf = (ctypes.c_uint64 * (2 * n))()
+    assert lib.rt_debug_read_stats(t.handle, buf, 1) == 0   # allocates + zeroes the counters
+    t.render_frames(0, frames)
+    t.synchronize()
+    assert lib.rt_debug_read_stats(t.handle, buf, 0) == 0
+    samples = 1920 * 1080 * 16 * frames
+    iters = buf[0]
+    out = {}
+    print("%-10s %14s %10s %12s %10s" % ("section", "wave execs", "per iter", "mean lanes", "lanes/64"))
+    for i, name in enumerate(SECTIONS):
+        ex, ln = buf[2 * i], buf[2 * i + 1]
+        mean = ln / ex if ex else 0.0
+        out[name] = {"wave_execs": int(ex), "lane_execs": int(ln)}
+        print("%-10s %14d %10.4f %12.2f %10.3f" % (name, ex, ex / iters if iters else 0, mean, mean / 64.0))
+    print("wave iterations per wave-sample: %.3f (ideal = segments/sample = 1.946)" % (iters / (samples / 64.0)))
+    json.dump({"frames": frames, "samples": samples, "sections": out}, open(os.path.join(ROOT, "gpurun_out", "section_stats.json"), "w"), indent=1)
+    t.destroy()
+
+
+if __name__ == "__main__":
+    main()

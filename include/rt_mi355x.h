@@ -184,6 +184,11 @@ int rt_probe_hit_sphere(int device_id, const rt_gpu_sphere *spheres, const float
                         float *out, int32_t *front);
 /* pow as the tracer evaluates it (schlick :196, tonemap :340). */
 int rt_probe_pow(int device_id, const float *x, const float *y, uint32_t n, float *out);
+/* The tracer's divide / sqrt / inversesqrt helpers (which skip the range-scaling steps of the IEEE
+ * sequences when the operands allow) next to the full sequences, element-wise: op 0: a / b,
+ * op 1: sqrt(a), op 2: 1 / sqrt(a).  Both outputs must equal the correctly rounded result. */
+int rt_probe_arith(int device_id, uint32_t op, const float *a, const float *b, uint32_t n, float *out_cheap,
+                   float *out_full);
 /* hash/lcg/rand, raytrace.comp.glsl:37-55: for each of n seeds (x,y,z) returns the
  * hash and the first `draws` lcg states. out: n x (1 + draws) words. */
 int rt_probe_rng(int device_id, const uint32_t *xyz, uint32_t n, uint32_t draws, uint32_t *out);

@@ -3,9 +3,9 @@
 The directory name carries a hyphen, so import it through rtamd_loader.load()
 (repo root), which registers it as the module `raytracing_amd`.
 """
-from .tracer import (ABI, GPUParams, GPUSphere, LIB_PATH, RayTracer, load_library, probe_hit_sphere, probe_pow,
-                     probe_rng)
+from .tracer import (ABI, GPUParams, GPUSphere, LIB_PATH, RayTracer, load_library, probe_arith, probe_hit_sphere,
+                     probe_pow, probe_rng)
 from .scene import default_scene, synthetic_scene
 
 __all__ = ["ABI", "GPUParams", "GPUSphere", "LIB_PATH", "RayTracer", "load_library", "probe_hit_sphere",
-           "probe_pow", "probe_rng", "default_scene", "synthetic_scene"]
+           "probe_pow", "probe_rng", "probe_arith", "default_scene", "synthetic_scene"]

@@ -29,8 +29,87 @@ __device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y
 // GLSL min/max: "y if y < x, otherwise x" / "y if x < y, otherwise x".
 __device__ __forceinline__ float glsl_min(float x, float y) { return (y < x) ? y : x; }
 __device__ __forceinline__ float glsl_max(float x, float y) { return (x < y) ? y : x; }
-// inversesqrt as two correctly rounded steps; normalize(v) = v * inversesqrt(dot(v,v)).
-__device__ __forceinline__ float inversesqrt(float x) { return 1.0f / sqrtf(x); }
+// ---------------------------------------------------------------- exact divide / sqrt, cheaper
+// `x / y` and sqrtf() compile to the full IEEE sequences (v_div_scale, v_rcp, five fma, v_div_fmas,
+// v_div_fixup; v_sqrt plus input scaling, a one-ulp correction and a class fix-up).  The scaling and
+// fix-up steps only matter for operands near the ends of the exponent range, and the denominator
+// half of a division (reciprocal + one Newton step) can be shared by every division with the same
+// denominator.  The helpers below run the same core arithmetic without those steps when the
+// operands are in a range where they are no-ops, and fall back to the full sequence otherwise, so
+// the result is the correctly rounded one in every case.
+// The fall-back blocks start with an empty `asm volatile`: it cannot be executed speculatively, so
+// the compiler keeps them behind a branch that is skipped when no lane needs them, instead of
+// computing both variants and selecting.
+#define RT_COLD_PATH() asm volatile("; full-range sequence" ::)
+constexpr float kDenLo = 0x1p-20f;  // denominators in [2^-20, 2^20]
+constexpr float kDenHi = 0x1p20f;
+constexpr float kNumLo = 0x1p-90f;  // numerators with 2^-90 <= |n| < 2^100
+constexpr float kNumHi = 0x1p100f;
+
+__device__ __forceinline__ bool den_in_range(float d) { return d >= kDenLo && d <= kDenHi; }
+__device__ __forceinline__ bool num_in_range(float n) { return fabsf(n) >= kNumLo && fabsf(n) < kNumHi; }
+
+// Denominator half of the division sequence: rcp and one Newton step.
+__device__ __forceinline__ float refined_rcp(float d)
+{
+    float r0 = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+// Numerator half: quotient estimate, two residual corrections.
+__device__ __forceinline__ float div_core(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+// n / d given r = refined_rcp(d) and d_ok = den_in_range(d).
+__device__ __forceinline__ float div_shared(float n, float d, float r, bool d_ok)
+{
+    float q = div_core(n, d, r);
+    if (!(d_ok && num_in_range(n))) {
+        RT_COLD_PATH();
+        q = n / d;
+    }
+    return q;
+}
+// Correctly rounded sqrt for 2^-90 <= x < 2^100 (v_sqrt_f32 is within one ulp; pick the neighbour
+// whose residual changes sign), full sequence otherwise.
+__device__ __forceinline__ float sqrt_core(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    float r_dn = __builtin_fmaf(-s_dn, s, x);
+    float r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    s = (r_up > 0.0f) ? s_up : s;
+    return s;
+}
+__device__ __forceinline__ float sqrt_exact(float x)
+{
+    float s = sqrt_core(x);
+    if (!(x >= kNumLo && x < kNumHi)) {
+        RT_COLD_PATH();
+        s = sqrtf(x);
+    }
+    return s;
+}
+// inversesqrt as two correctly rounded steps (sqrt, then 1/s); normalize(v) = v * inversesqrt(dot(v,v)).
+__device__ __forceinline__ float inversesqrt(float x)
+{
+    // 2^-40 <= x <= 2^40 keeps both the sqrt and the reciprocal of its result inside the cheap ranges
+    float s = sqrt_core(x);
+    float q = div_core(1.0f, s, refined_rcp(s));
+    if (!(x >= 0x1p-40f && x <= 0x1p40f)) {
+        RT_COLD_PATH();
+        q = 1.0f / sqrtf(x);
+    }
+    return q;
+}
+__device__ __forceinline__ f3 normalize_with_dot(f3 a, float d2) { return a * inversesqrt(d2); }
 __device__ __forceinline__ f3 normalize(f3 a) { return a * inversesqrt(dot(a, a)); }
 // reflect(I, N) = I - 2.0 * dot(N, I) * N
 __device__ __forceinline__ f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(n, i)); }
@@ -165,22 +244,59 @@ __device__ __forceinline__ void random_in_unit_disk(uint32_t& rng, float& dx, fl
 }
 
 // ---------------------------------------------------------------- intersection
-// The root-finding half of hitSphere, raytrace.comp.glsl:111-133.  geom = (centre, radius^2);
-// a = dot(d,d) is the same for every sphere of one ray and is passed in.
-// Returns true and the accepted root when the sphere is hit inside [tmin, tmax].
-__device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, float a, float tmin, float tmax, float& root_out)
+// Per-ray constants of the intersection: a = dot(d,d) (the same for every sphere, :112), the shared
+// denominator half of the two root divisions, and whether `a` is in the cheap-division range.
+struct RayDenominator {
+    float a;
+    float rcp_a;
+    bool a_ok;
+};
+__device__ __forceinline__ RayDenominator ray_denominator(f3 d)
+{
+    RayDenominator r;
+    r.a = dot(d, d);
+    r.rcp_a = refined_rcp(r.a);
+    r.a_ok = den_in_range(r.a);
+    return r;
+}
+// (-half_b -/+ sqrt_disc) / a, :123 and :127.  A numerator below 2^-90 in magnitude gives a root
+// far below tmin = 0.001 whichever way it is rounded, and such a root is rejected and never
+// stored, so only the upper end of the numerator range needs the full division.
+__device__ __forceinline__ float root_div(float n, const RayDenominator& rd)
+{
+    float q = div_core(n, rd.a, rd.rcp_a);
+    if (!(rd.a_ok && fabsf(n) < kNumHi)) {
+        RT_COLD_PATH();
+        q = n / rd.a;
+    }
+    return q;
+}
+
+// The root-finding half of hitSphere, raytrace.comp.glsl:111-133.  geom = (centre, radius^2).
+// Returns true and the accepted root when the sphere is hit inside [tmin, tmax]; tmin must be > 0.
+template <class Stats>
+__device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, const RayDenominator& rden, float tmin, float tmax,
+                                            float& root_out, Stats& st)
 {
     f3 oc = o - mk(geom.x, geom.y, geom.z);
     float half_b = dot(oc, d);
     float c = dot(oc, oc) - geom.w;
-    float discriminant = half_b * half_b - a * c;
+    float discriminant = half_b * half_b - rden.a * c;
     if (discriminant < 0.0f) {
         return false;
     }
-    float sqrt_disc = sqrtf(discriminant);
-    float root = (-half_b - sqrt_disc) / a;
+    // Origin outside the sphere and moving away from it (half_b > 0, c > 0, both below 2^59, a
+    // positive and finite): sqrt_disc <= half_b, so both roots are <= 0 < tmin and :125-131 reject
+    // them.  Positive floats order like their bit patterns, so one unsigned compare tests both.
+    if (rden.a_ok && (__float_as_uint(half_b) | __float_as_uint(c)) < 0x5D000000u) {
+        return false;
+    }
+    st.section(5 /* ST_ROOT */);
+    float sqrt_disc = sqrt_exact(discriminant);
+    float root = root_div(-half_b - sqrt_disc, rden);
     if (root < tmin || root > tmax) {
-        root = (-half_b + sqrt_disc) / a;
+        st.section(6 /* ST_FAR_ROOT */);
+        root = root_div(-half_b + sqrt_disc, rden);
         if (root < tmin || root > tmax) {
             return false;
         }
@@ -193,7 +309,17 @@ __device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, float a, fl
 __device__ __forceinline__ void hit_finish(f3 centre, float radius, f3 o, f3 d, float t, f3& p, f3& n, bool& front)
 {
     p = o + d * t;
-    n = (p - centre) / radius;
+    const f3 pc = p - centre;
+    // n = (p - centre) / radius: three divisions by one denominator
+    const float rr = refined_rcp(radius);
+    const bool r_ok = den_in_range(radius);
+    const float lo = fminf(fminf(fabsf(pc.x), fabsf(pc.y)), fabsf(pc.z));
+    const float hi = fmaxf(fmaxf(fabsf(pc.x), fabsf(pc.y)), fabsf(pc.z));
+    n = mk(div_core(pc.x, radius, rr), div_core(pc.y, radius, rr), div_core(pc.z, radius, rr));
+    if (!(r_ok && lo >= kNumLo && hi < kNumHi)) {
+        RT_COLD_PATH();
+        n = pc / radius;
+    }
     front = dot(d, n) < 0.0f;
     if (!front) {
         n = -n;

@@ -938,6 +938,28 @@ int rt_probe_pow(int device_id, const float* x, const float* y, uint32_t n, floa
     });
 }
 
+int rt_probe_arith(int device_id, uint32_t op, const float* a, const float* b, uint32_t n, float* out_cheap, float* out_full)
+{
+    if (!a || !b || !out_cheap || !out_full || n == 0 || op > 2) {
+        return fail_arg(nullptr, "probe arguments");
+    }
+    return with_device(device_id, [&]() -> int {
+        DeviceBuffer da, db, dout;
+        rt_tracer* none = nullptr;
+        const size_t bytes = static_cast<size_t>(n) * sizeof(float);
+        RT_HIP_TRY(none, da.alloc(bytes));
+        RT_HIP_TRY(none, db.alloc(bytes));
+        RT_HIP_TRY(none, dout.alloc(2 * bytes));
+        RT_HIP_TRY(none, hipMemcpy(da.ptr, a, bytes, hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, hipMemcpy(db.ptr, b, bytes, hipMemcpyHostToDevice));
+        RT_HIP_TRY(none, rt::launch_probe_arith(op, static_cast<float*>(da.ptr), static_cast<float*>(db.ptr), n,
+                                                static_cast<float*>(dout.ptr), nullptr));
+        RT_HIP_TRY(none, hipMemcpy(out_cheap, dout.ptr, bytes, hipMemcpyDeviceToHost));
+        RT_HIP_TRY(none, hipMemcpy(out_full, static_cast<float*>(dout.ptr) + n, bytes, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
+}
+
 int rt_probe_rng(int device_id, const uint32_t* xyz, uint32_t n, uint32_t draws, uint32_t* out)
 {
     if (!xyz || !out || n == 0) {

@@ -271,29 +271,12 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
         // ------------------------------------------------------------------ closest hit, :244-259
         float closest = 1e20f;
         int best = -1;
-        {
-            const float a = dot(rd, rd);
-            for (uint32_t i = 0; i < sphere_count; ++i) {
-                const float4 g = geom[i];
-                f3 oc = ro - mk(g.x, g.y, g.z);
-                float half_b = dot(oc, rd);
-                float c = dot(oc, oc) - g.w;
-                float discriminant = half_b * half_b - a * c;
-                if (!(discriminant < 0.0f)) { // :117
-                    st.section(ST_ROOT);
-                    float sqrt_disc = sqrtf(discriminant);
-                    float root = (-half_b - sqrt_disc) / a;
-                    bool ok = true;
-                    if (root < kTMin || root > closest) { // :125
-                        st.section(ST_FAR_ROOT);
-                        root = (-half_b + sqrt_disc) / a;
-                        ok = !(root < kTMin || root > closest); // :129
-                    }
-                    if (ok) {
-                        closest = root;
-                        best = (int)i;
-                    }
-                }
+        const RayDenominator rden = ray_denominator(rd);
+        for (uint32_t i = 0; i < sphere_count; ++i) {
+            float root;
+            if (sphere_root(geom[i], ro, rd, rden, kTMin, closest, root, st)) {
+                closest = root;
+                best = (int)i;
             }
         }
         const bool hit = best >= 0;
@@ -459,7 +442,8 @@ __global__ void rt_probe_hit_kernel(const rt_gpu_sphere* spheres, const float* r
     float4 geom = make_float4(s.center_radius[0], s.center_radius[1], s.center_radius[2], radius * radius);
     float root = 0.0f;
     float* o8 = out + (size_t)i * 8;
-    bool hit = sphere_root(geom, o, d, dot(d, d), tmin, tmax, root);
+    NoStats nost;
+    bool hit = sphere_root(geom, o, d, ray_denominator(d), tmin, tmax, root, nost);
     f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
     bool front = false;
     if (hit) {
@@ -478,6 +462,30 @@ __global__ void rt_probe_pow_kernel(const float* x, const float* y, uint32_t n, 
     if (i < n) {
         out[i] = glsl_pow(x[i], y[i]);
     }
+}
+
+// out[0..n) = the cheap-range helper, out[n..2n) = the full IEEE sequence, for op:
+// 0: a / b (div_shared)   1: sqrt(a)   2: inversesqrt(a) = 1 / sqrt(a)
+__global__ void rt_probe_arith_kernel(uint32_t op, const float* a, const float* b, uint32_t n, float* out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const float x = a[i], y = b[i];
+    float cheap, full;
+    if (op == 0u) {
+        cheap = div_shared(x, y, refined_rcp(y), den_in_range(y));
+        full = x / y;
+    } else if (op == 1u) {
+        cheap = sqrt_exact(x);
+        full = sqrtf(x);
+    } else {
+        cheap = inversesqrt(x);
+        full = 1.0f / sqrtf(x);
+    }
+    out[i] = cheap;
+    out[n + i] = full;
 }
 
 __global__ void rt_probe_rng_kernel(const uint32_t* xyz, uint32_t n, uint32_t draws, uint32_t* out)
@@ -582,6 +590,12 @@ hipError_t launch_probe_hit(const rt_gpu_sphere* spheres, const float* rays, uin
 hipError_t launch_probe_pow(const float* x, const float* y, uint32_t n, float* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(rt_probe_pow_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_arith(uint32_t op, const float* a, const float* b, uint32_t n, float* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_probe_arith_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, n, out);
     return hipGetLastError();
 }
 

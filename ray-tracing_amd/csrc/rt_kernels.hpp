@@ -51,6 +51,7 @@ hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first,
 hipError_t launch_probe_hit(const rt_gpu_sphere* spheres, const float* rays, uint32_t n, float* out,
                             int32_t* front, hipStream_t stream);
 hipError_t launch_probe_pow(const float* x, const float* y, uint32_t n, float* out, hipStream_t stream);
+hipError_t launch_probe_arith(uint32_t op, const float* a, const float* b, uint32_t n, float* out, hipStream_t stream);
 hipError_t launch_probe_rng(const uint32_t* xyz, uint32_t n, uint32_t draws, uint32_t* out, hipStream_t stream);
 
 } // namespace rt

@@ -81,6 +81,8 @@ ABI = {
     "rt_probe_hit_sphere": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(GPUSphere), ctypes.c_void_p, _U32,
                                            ctypes.c_void_p, ctypes.c_void_p]),
     "rt_probe_pow": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.c_void_p]),
+    "rt_probe_arith": (ctypes.c_int, [ctypes.c_int, _U32, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.c_void_p,
+                                      ctypes.c_void_p]),
     "rt_probe_rng": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, _U32, _U32, ctypes.c_void_p]),
 }
 
@@ -306,6 +308,20 @@ def probe_pow(x, y, device_id=0):
     if rc != 0:
         raise RuntimeError("rt_probe_pow failed: %s" % lib.rt_last_error(None).decode())
     return out
+
+
+def probe_arith(op, a, b=None, device_id=0):
+    """op 0: a / b, 1: sqrt(a), 2: 1 / sqrt(a) -> (cheap-range helper result, full IEEE sequence result)."""
+    lib = load_library()
+    xa = np.ascontiguousarray(a, dtype=np.float32).ravel()
+    xb = np.ascontiguousarray(b if b is not None else np.ones_like(xa), dtype=np.float32).ravel()
+    assert xa.size == xb.size
+    cheap = np.empty_like(xa)
+    full = np.empty_like(xa)
+    rc = lib.rt_probe_arith(device_id, op, xa.ctypes.data, xb.ctypes.data, xa.size, cheap.ctypes.data, full.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("rt_probe_arith failed: %s" % lib.rt_last_error(None).decode())
+    return cheap, full
 
 
 def probe_rng(xyz, draws, device_id=0):

@@ -76,6 +76,61 @@ def test_pow_bits_match_oracle(pkg, oracle):
         assert same(got, want)
 
 
+def _same_or_both_nan(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    bad = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+    if bad.any():
+        i = int(np.argmax(bad))
+        pytest.fail("%d of %d differ, first at %d: %r (0x%08x) vs %r (0x%08x)" % (
+            int(bad.sum()), a.size, i, a[i], a.view(np.uint32)[i], b[i], b.view(np.uint32)[i]), pytrace=False)
+    return True
+
+
+def test_cheap_divide_and_sqrt_are_correctly_rounded(pkg):
+    # The tracer's divide/sqrt helpers skip the range-scaling steps of the IEEE sequences when the
+    # operands allow.  They must give the correctly rounded result (numpy float32 = IEEE) for every
+    # input: random bit patterns over the whole exponent range, the ranges the tracer lives in, and
+    # values around the range limits where the helpers switch to the full sequence.
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    old = np.seterr(all="ignore")
+    try:
+        def patterns(m):
+            return rng.integers(0, 2**32, size=m, dtype=np.uint64).astype(np.uint32).view(np.float32)
+
+        def typical(m, lo, hi):
+            return (np.exp(rng.uniform(np.log(lo), np.log(hi), size=m)) * rng.choice([-1.0, 1.0], size=m)).astype(np.float32)
+
+        edges = np.float32([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 2.0**-20, 2.0**20, 2.0**-90, 2.0**100,
+                            2.0**-40, 2.0**40, 1e-45, 1e-38, 3e38, 2.0**-126, 2.0**-127, 0.99999994, 1.0000001,
+                            np.nextafter(np.float32(2.0**-20), np.float32(0)), np.nextafter(np.float32(2.0**20), np.float32(np.inf)),
+                            np.nextafter(np.float32(2.0**-90), np.float32(0)), np.nextafter(np.float32(2.0**100), np.float32(0)),
+                            np.nextafter(np.float32(2.0**-40), np.float32(0)), np.nextafter(np.float32(2.0**40), np.float32(np.inf))])
+        ea, eb = np.meshgrid(edges, edges)
+        # division
+        for a, b in [(patterns(n), patterns(n)),
+                     (typical(n, 1e-6, 1e6), typical(n, 1e-3, 1e3)),
+                     (typical(n, 1e-30, 1e30), np.abs(typical(n, 0.5, 2.0))),
+                     (ea.ravel(), eb.ravel())]:
+            cheap, full = pkg.probe_arith(0, a, b)
+            want = a / b
+            assert _same_or_both_nan(full, want)
+            assert _same_or_both_nan(cheap, want)
+        # sqrt and 1/sqrt
+        for a in [np.abs(patterns(n)), patterns(n), np.abs(typical(n, 1e-12, 1e12)), np.abs(typical(n, 0.25, 4.0)), edges]:
+            cheap, full = pkg.probe_arith(1, a)
+            want = np.sqrt(a)
+            assert _same_or_both_nan(full, want)
+            assert _same_or_both_nan(cheap, want)
+            cheap, full = pkg.probe_arith(2, a)
+            want = np.float32(1.0) / np.sqrt(a)
+            assert _same_or_both_nan(full, want)
+            assert _same_or_both_nan(cheap, want)
+    finally:
+        np.seterr(**old)
+
+
 def test_hit_sphere_vectors(pkg, oracle):
     rng = np.random.default_rng(7)
     n = 6000

@@ -291,7 +291,8 @@ int fail_no_device(rt_tracer* h)
 
 bool valid_extent(uint32_t w, uint32_t hgt)
 {
-    return w >= 1 && hgt >= 1 && w <= 65536u && hgt <= 65536u;
+    // the kernels index texels with 32 bits
+    return w >= 1 && hgt >= 1 && w <= 65536u && hgt <= 65536u && static_cast<uint64_t>(w) * hgt < (1ull << 32);
 }
 
 int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
@@ -834,13 +835,14 @@ float rt_last_kernel_ms(rt_handle h)
 // Diagnostic builds only: per-section (wave executions, active lanes) pairs accumulated since the
 // handle was created; out receives 2 * rt_debug_stats_sections() 64-bit counters.
 int rt_debug_stats_sections(void) { return rt::stats_section_count(); }
+int rt_debug_stats_phases(void) { return rt::stats_phase_count(); }
 int rt_debug_read_stats(rt_handle h, unsigned long long* out, int reset)
 {
     if (h == nullptr || h->device < 0 || out == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
     }
     DeviceScope scope(h->device);
-    const size_t bytes = sizeof(unsigned long long) * 2 * rt::stats_section_count();
+    const size_t bytes = sizeof(unsigned long long) * (2 * rt::stats_section_count() + rt::stats_phase_count());
     if (h->stats == nullptr) {
         RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->stats), bytes));
         RT_HIP_TRY(h, hipMemset(h->stats, 0, bytes));

@@ -53,20 +53,45 @@ enum Section {
     ST_SKY, ST_LAMBERT, ST_CHECKER, ST_METAL, ST_DIEL, ST_SCHLICK, ST_COUNT
 };
 
+enum Phase { PH_NORM2, PH_INTERSECT, PH_HIT, PH_ITEM, PH_SAMPLER, PH_NORM1, PH_SHADE, PH_TAIL, PH_COUNT };
+
 struct NoStats {
     __device__ __forceinline__ void section(int) {}
+    __device__ __forceinline__ void phase_start() {}
+    __device__ __forceinline__ void phase_end(int) {}
     __device__ __forceinline__ void flush(uint32_t*) {}
 };
 
 struct WaveStats {
     uint32_t exec[ST_COUNT];
     uint32_t lanes[ST_COUNT];
+    unsigned long long phase_cycles[PH_COUNT]; // shader-clock cycles between phase marks (wave-uniform)
+    unsigned long long last;
     __device__ __forceinline__ WaveStats()
     {
         for (int i = 0; i < ST_COUNT; ++i) {
             exec[i] = 0;
             lanes[i] = 0;
         }
+        for (int i = 0; i < PH_COUNT; ++i) {
+            phase_cycles[i] = 0;
+        }
+        last = 0;
+    }
+    static __device__ __forceinline__ unsigned long long stamp()
+    {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    }
+    __device__ __forceinline__ void phase_start() { last = stamp(); }
+    __device__ __forceinline__ void phase_end(int k)
+    {
+        unsigned long long t = stamp();
+        phase_cycles[k] += t - last;
+        last = t;
     }
     __device__ __forceinline__ void section(int k)
     {
@@ -87,6 +112,11 @@ struct WaveStats {
             }
             if (lanes[i]) {
                 atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * i + 1, (unsigned long long)lanes[i]);
+            }
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            for (int i = 0; i < PH_COUNT; ++i) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(out) + 2 * ST_COUNT + i, phase_cycles[i]);
             }
         }
     }
@@ -165,13 +195,13 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
 
     // ---- per-lane state ----
     bool has_item = false;
-    bool ended = true;        // the current path is over: start the next sample (or the next item)
+    bool live = false;         // the lane carries a ray that has to be traced in this iteration
     bool pending_norm = false; // rd still has to be normalized (camera ray :328, lambert :159)
     uint32_t samples_left = 0;
-    uint32_t rel = 0;         // frame of the current item, relative to first_frame
+    uint32_t rel = 0;          // frame of the current item, relative to first_frame
     uint32_t rng = 0;
     uint32_t depth = 0;
-    size_t texel = 0;
+    uint32_t texel = 0;        // py * width + px (the host keeps width * height below 2^32)
     float fpx = 0.0f, fpy_flipped = 0.0f;
     f3 frame_sum = mk(0.0f, 0.0f, 0.0f); // `accum` of :313
     f3 ro = origin, rd = origin;
@@ -179,88 +209,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
 
     for (;;) {
         st.section(ST_ITER);
-        // ------------------------------------------------------------------ item bookkeeping
-        const bool need_item = ended && samples_left == 0u;
-        if (need_item && has_item) {
-            // one dispatch's worth of this pixel is done: :333-335
-            if (A.partial != nullptr) {
-                A.partial[(size_t)rel * image_pixels + texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
-            } else {
-                const float4 prev = A.accum[texel];
-                const f3 total = mk(prev.x, prev.y, prev.z) + frame_sum;
-                A.accum[texel] = make_float4(total.x, total.y, total.z, 1.0f);
-                if (A.output != nullptr) {
-                    // :337 (frame + 1u) * spp wraps in uint32 before the conversion
-                    const uint32_t frame = A.first_frame + rel * A.frame_stride;
-                    A.output[texel] = tonemap_rgba8(total, (float)((frame + 1u) * spp_raw));
-                }
-            }
-            if (A.rng_out != nullptr && rel + 1u == A.n_frames) {
-                A.rng_out[texel] = rng;
-            }
-        }
-        // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
-        const unsigned long long want = __ballot(need_item);
-        const uint32_t my_item = next_item + lane_prefix(want);
-        next_item += (uint32_t)__popcll(want);
-        if (need_item) {
-            if (my_item >= n_items) {
-                break; // pool drained: this lane is done
-            }
-            st.section(ST_ITEM);
-            uint32_t frame_in_chunk, pix;
-            if (tile_pixels == 64u) {
-                frame_in_chunk = my_item >> 6;
-                pix = my_item & 63u;
-            } else {
-                frame_in_chunk = my_item / tile_pixels;
-                pix = my_item - frame_in_chunk * tile_pixels;
-            }
-            uint32_t ly, lx;
-            if (tile_w == 8u) {
-                ly = pix >> 3;
-                lx = pix & 7u;
-            } else {
-                ly = pix / tile_w;
-                lx = pix - ly * tile_w;
-            }
-            const uint32_t px = x0 + lx;
-            const uint32_t py = y0 + ly;
-            rel = rel_begin + frame_in_chunk;
-            texel = (size_t)py * A.width + px;
-            fpx = (float)(int32_t)px;
-            fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
-            rng = hash3(px, py, A.first_frame + rel * A.frame_stride); // :310-311
-            samples_left = spp;
-            frame_sum = mk(0.0f, 0.0f, 0.0f);
-            has_item = true;
-        }
-
-        // ------------------------------------------------------------------ camera ray, :317-328
-        if (ended) {
-            st.section(ST_GEN);
-            --samples_left;
-            float u_coord = (fpx + rnd(rng)) * inv_w;
-            float v_coord = (fpy_flipped + rnd(rng)) * inv_h;
-            float dx, dy;
-            do {
-                st.section(ST_DISK_IT);
-                float a = rnd(rng);
-                float b = rnd(rng);
-                dx = a * 2.0f - 1.0f;
-                dy = b * 2.0f - 1.0f;
-            } while ((dx * dx + dy * dy) >= 1.0f); // :75-86
-            float rdx = lens_radius * dx;
-            float rdy = lens_radius * dy;
-            f3 offset = cam_u * rdx + cam_v * rdy;
-            rd = lower_left + horizontal * u_coord + vertical * v_coord - origin - offset;
-            ro = origin + offset;
-            pending_norm = true;
-            throughput = mk(1.0f, 1.0f, 1.0f);
-            depth = 0u;
-            ended = false;
-        }
-
+        st.phase_start();
         // ------------------------------------------------------------------ merged normalize #2
         if (pending_norm) {
             st.section(ST_NORM2);
@@ -268,18 +217,27 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
             pending_norm = false;
         }
 
+        st.phase_end(PH_NORM2);
         // ------------------------------------------------------------------ closest hit, :244-259
         float closest = 1e20f;
         int best = -1;
-        const RayDenominator rden = ray_denominator(rd);
-        for (uint32_t i = 0; i < sphere_count; ++i) {
-            float root;
-            if (sphere_root(geom[i], ro, rd, rden, kTMin, closest, root, st)) {
-                closest = root;
-                best = (int)i;
+        RayDenominator rden;
+        rden.a = 1.0f;
+        rden.rcp_a = 1.0f;
+        rden.a_ok = true;
+        if (live) {
+            rden = ray_denominator(rd);
+            for (uint32_t i = 0; i < sphere_count; ++i) {
+                float root;
+                if (sphere_root(geom[i], ro, rd, rden, kTMin, closest, root, st)) {
+                    closest = root;
+                    best = (int)i;
+                }
             }
         }
-        const bool hit = best >= 0;
+        st.phase_end(PH_INTERSECT);
+        const bool hit = best >= 0; // only live lanes can hit
+        const bool miss = live && !hit;
 
         // ------------------------------------------------------------------ winner's record, :135-149
         f3 p = ro, n = ro, albedo = ro;
@@ -309,27 +267,104 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
         }
         const bool is_lambert = hit && mat == 0u;
         const bool is_metal = hit && mat == 1u;
+        st.phase_end(PH_HIT);
 
-        // ------------------------------------------------------------------ shared rejection sampler
-        f3 ris = ro;
-        if (is_lambert || is_metal) {
-            st.section(ST_RIS);
-            do {
-                st.section(ST_RIS_IT);
-                float a = rnd(rng);
-                float b = rnd(rng);
-                float c = rnd(rng);
-                ris = mk(a * 2.0f - 1.0f, b * 2.0f - 1.0f, c * 2.0f - 1.0f);
-            } while (dot(ris, ris) >= 1.0f); // :57-68
+        // ------------------------------------------------------------------ item bookkeeping
+        // Lanes whose path is over (it ended earlier, or it just left the scene) start their next
+        // camera ray in this iteration.  If the item has no samples left it is complete, apart from
+        // the sky term a missing lane adds below: fetch the next item now (its random stream has to
+        // exist before the samplers run) and write the finished one out after the shading.
+        const bool regen = !live || miss;
+        const bool need_item = regen && samples_left == 0u;
+        const bool write_out = need_item && has_item;
+        const uint32_t old_texel = texel;
+        const uint32_t old_rel = rel;
+        if (write_out && A.rng_out != nullptr && rel + 1u == A.n_frames) {
+            A.rng_out[texel] = rng;
+        }
+        // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
+        const unsigned long long want = __ballot(need_item);
+        const uint32_t my_item = next_item + lane_prefix(want);
+        next_item += (uint32_t)__popcll(want);
+        const bool exiting = need_item && my_item >= n_items; // pool drained: leave after the write-out
+        if (need_item && !exiting) {
+            st.section(ST_ITEM);
+            uint32_t frame_in_chunk, pix;
+            if (tile_pixels == 64u) {
+                frame_in_chunk = my_item >> 6;
+                pix = my_item & 63u;
+            } else {
+                frame_in_chunk = my_item / tile_pixels;
+                pix = my_item - frame_in_chunk * tile_pixels;
+            }
+            uint32_t ly, lx;
+            if (tile_w == 8u) {
+                ly = pix >> 3;
+                lx = pix & 7u;
+            } else {
+                ly = pix / tile_w;
+                lx = pix - ly * tile_w;
+            }
+            const uint32_t px = x0 + lx;
+            const uint32_t py = y0 + ly;
+            rel = rel_begin + frame_in_chunk;
+            texel = py * A.width + px;
+            fpx = (float)(int32_t)px;
+            fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
+            rng = hash3(px, py, A.first_frame + rel * A.frame_stride); // :310-311
+            samples_left = spp;
+            has_item = true;
+        }
+        const bool gen = regen && !exiting; // this lane draws a camera sample now
+
+        // ------------------------------------------------------------------ pixel jitter, :317-320
+        float u_coord = 0.0f, v_coord = 0.0f;
+        if (gen) {
+            st.section(ST_GEN);
+            --samples_left;
+            u_coord = (fpx + rnd(rng)) * inv_w;
+            v_coord = (fpy_flipped + rnd(rng)) * inv_h;
         }
 
-        // ------------------------------------------------------------------ merged normalize #1
-        // lambert: randomUnitVector = normalize(ris), :72.  everything else: normalize(ray.d),
-        // :201 (metal), :215 (dielectric), :263 (sky).
-        const f3 unit = normalize(is_lambert ? ris : rd);
+        st.phase_end(PH_ITEM);
+        // ------------------------------------------------------------------ shared rejection sampler
+        // randomInUnitDisk (:75-86) for the lanes that start a camera ray, randomInUnitSphere (:57-68)
+        // for lambert and metal lanes, in one loop.  A draw r = k / 2^24 gives 2r - 1 = (k - 2^23) / 2^23
+        // exactly, so the candidate is kept as the integer-valued floats m = k - 2^23 and the test
+        // dot(p,p) >= 1 becomes (mx*mx + my*my) + mz*mz >= 2^46 (scaling by a power of two commutes
+        // with every rounding involved).  Disk lanes take no third draw: their multiplier/increment
+        // are (1, 0) and their mz is 0, which adds +0 to the two-term sum of :83.
+        const bool want3 = is_lambert || is_metal;
+        float mx = 0.0f, my = 0.0f, mz = 0.0f, m_dot = 0.0f;
+        if (gen || want3) {
+            st.section(ST_RIS);
+            const uint32_t mul3 = want3 ? 1664525u : 1u;
+            const uint32_t add3 = want3 ? 1013904223u : 0u;
+            const uint32_t mask3 = want3 ? 0x00FFFFFFu : 0u;
+            const int32_t off3 = want3 ? 0x00800000 : 0;
+            do {
+                st.section(ST_RIS_IT);
+                const uint32_t s1 = 1664525u * rng + 1013904223u;
+                const uint32_t s2 = 1664525u * s1 + 1013904223u;
+                rng = mul3 * s2 + add3;
+                mx = (float)((int32_t)(s1 & 0x00FFFFFFu) - 0x00800000);
+                my = (float)((int32_t)(s2 & 0x00FFFFFFu) - 0x00800000);
+                mz = (float)((int32_t)(rng & mask3) - off3);
+                m_dot = (mx * mx + my * my) + mz * mz;
+            } while (m_dot >= 0x1p46f);
+        }
+        const f3 ris = mk(mx * 0x1p-23f, my * 0x1p-23f, mz * 0x1p-23f);
+        st.phase_end(PH_SAMPLER);
 
+        // ------------------------------------------------------------------ merged normalize #1
+        // lambert: randomUnitVector = normalize(ris), :72, whose dot(ris,ris) is the sampler's last sum.
+        // everything else: normalize(ray.d), :201 (metal), :215 (dielectric), :263 (sky), whose
+        // dot(d,d) is the `a` of the intersection.
+        const f3 unit = (is_lambert ? ris : rd) * inversesqrt(is_lambert ? m_dot * 0x1p-46f : rden.a);
+
+        st.phase_end(PH_NORM1);
         bool scattered = true;
-        if (!hit) {
+        if (miss) {
             // sky, :261-269
             st.section(ST_SKY);
             float t = 0.5f * (unit.y + 1.0f);
@@ -337,7 +372,6 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
             f3 sky = mk(omt + 0.5f * t, omt + 0.7f * t, omt + 1.0f * t);
             f3 radiance = mk(0.0f, 0.0f, 0.0f) + throughput * sky;
             frame_sum = frame_sum + radiance; // :330
-            ended = true;
         } else if (is_lambert) {
             // scatterLambert, :155-174
             st.section(ST_LAMBERT);
@@ -361,7 +395,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
             rd = reflected + ris * fuzz;
             throughput = throughput * albedo;
             scattered = dot(rd, n) > 0.0f;
-        } else {
+        } else if (hit) {
             // scatterDielectric, :210-234
             st.section(ST_DIEL);
             throughput = throughput * mk(1.0f, 1.0f, 1.0f);
@@ -385,9 +419,44 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
         if (hit) {
             ++depth;
             if (!scattered || depth >= max_depth) {
-                ended = true; // :287-290 break, or the bounce budget of :242 is spent
+                live = false; // :287-290 break, or the bounce budget of :242 is spent
             }
         }
+
+        st.phase_end(PH_SHADE);
+        // ------------------------------------------------------------------ finished item, :333-335
+        if (write_out) {
+            if (A.partial != nullptr) {
+                A.partial[(size_t)old_rel * image_pixels + old_texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
+            } else {
+                const float4 prev = A.accum[old_texel];
+                const f3 total = mk(prev.x, prev.y, prev.z) + frame_sum;
+                A.accum[old_texel] = make_float4(total.x, total.y, total.z, 1.0f);
+                if (A.output != nullptr) {
+                    // :337 (frame + 1u) * spp wraps in uint32 before the conversion
+                    const uint32_t frame = A.first_frame + old_rel * A.frame_stride;
+                    A.output[old_texel] = tonemap_rgba8(total, (float)((frame + 1u) * spp_raw));
+                }
+            }
+            frame_sum = mk(0.0f, 0.0f, 0.0f);
+        }
+        if (exiting) {
+            break;
+        }
+
+        // ------------------------------------------------------------------ camera ray, :322-328
+        if (gen) {
+            float rdx = lens_radius * ris.x;
+            float rdy = lens_radius * ris.y;
+            f3 offset = cam_u * rdx + cam_v * rdy;
+            rd = lower_left + horizontal * u_coord + vertical * v_coord - origin - offset;
+            ro = origin + offset;
+            pending_norm = true;
+            throughput = mk(1.0f, 1.0f, 1.0f);
+            depth = 0u;
+            live = true;
+        }
+        st.phase_end(PH_TAIL);
     }
     st.flush(A.stats);
 }
@@ -570,6 +639,7 @@ hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, s
 }
 
 int stats_section_count() { return ST_COUNT; }
+int stats_phase_count() { return PH_COUNT; }
 
 hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first, uint32_t count, float sample_count, hipStream_t stream)
 {

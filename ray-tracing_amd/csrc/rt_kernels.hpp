@@ -46,6 +46,7 @@ hipError_t launch_trace(const TraceArgs& args, hipStream_t stream);
 hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, size_t image_pixels, size_t first,
                        uint32_t count, uint32_t n_frames, float sample_count, hipStream_t stream);
 int stats_section_count();
+int stats_phase_count();
 hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first, uint32_t count,
                           float sample_count, hipStream_t stream);
 hipError_t launch_probe_hit(const rt_gpu_sphere* spheres, const float* rays, uint32_t n, float* out,

@@ -32,7 +32,9 @@ def main():
     t.set_samples_per_pixel(16)
     t.set_max_depth(8)
     t.set_aperture(0.0)
-    buf = (ctypes.c_uint64 * (2 * n))()
+    lib.rt_debug_stats_phases.restype = ctypes.c_int
+    nph = lib.rt_debug_stats_phases()
+    buf = (ctypes.c_uint64 * (2 * n + nph))()
     assert lib.rt_debug_read_stats(t.handle, buf, 1) == 0   # allocates + zeroes the counters
     t.render_frames(0, frames)
     t.synchronize()
@@ -46,6 +48,13 @@ def main():
         mean = ln / ex if ex else 0.0
         out[name] = {"wave_execs": int(ex), "lane_execs": int(ln)}
         print("%-10s %14d %10.4f %12.2f %10.3f" % (name, ex, ex / iters if iters else 0, mean, mean / 64.0))
+    phases = ["norm2", "intersect", "hit", "item+jitter", "sampler", "norm1", "shade", "tail(write+camera)"]
+    cyc = [buf[2 * n + i] for i in range(nph)]
+    tot = float(sum(cyc))
+    print("phase shares of one wave's timeline (shader-clock cycles between stamps; a stamp costs ~40 cycles):")
+    for name, c in zip(phases, cyc):
+        print("  %-20s %6.1f %%   %8.1f cycles/iteration" % (name, 100.0 * c / tot, c / iters))
+    out["_phases"] = dict(zip(phases, [int(c) for c in cyc]))
     print("wave iterations per wave-sample: %.3f (ideal = segments/sample = 1.946)" % (iters / (samples / 64.0)))
     json.dump({"frames": frames, "samples": samples, "sections": out}, open(os.path.join(ROOT, "gpurun_out", "section_stats.json"), "w"), indent=1)
     t.destroy()

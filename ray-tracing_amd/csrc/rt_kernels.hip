@@ -229,7 +229,13 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
             rden = ray_denominator(rd);
             for (uint32_t i = 0; i < sphere_count; ++i) {
                 float root;
-                if (sphere_root(geom[i], ro, rd, rden, kTMin, closest, root, st)) {
+#ifdef RT_GEOM_SCALAR
+                const float4 cr = reinterpret_cast<const float4*>(A.spheres)[3u * i];
+                const float4 gi = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
+#else
+                const float4 gi = geom[i];
+#endif
+                if (sphere_root(gi, ro, rd, rden, kTMin, closest, root, st)) {
                     closest = root;
                     best = (int)i;
                 }

@@ -32,6 +32,20 @@ def load_flops_per_sample():
         return json.load(f)["c2_1080p_spp16_depth8_dof_off"]["flops_per_sample"]
 
 
+def load_measured_traffic():
+    """HBM bytes per trace launch from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE); None if not recorded."""
+    best = None
+    base = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(base)):
+        path = os.path.join(base, name, "pmc_summary.json")
+        if os.path.isfile(path):
+            d = json.load(open(path)).get("_derived", {})
+            if "hbm_read_bytes_per_launch" in d:
+                best = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    return best
+
+
 def cpu_baseline(pkg, frames=24):
     """The CPU oracle (a port of the reference shader) timed on this machine's host cores on a bounded
     sample of the same workload."""
@@ -60,6 +74,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the multi-GPU code path (process group, all-reduce, resolve) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -73,13 +89,14 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus %d needs a torch.distributed launch with that many ranks" % args.gpus)
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     tracer = pkg.RayTracer().create(WIDTH, HEIGHT, device_id=local_rank)
     tracer.set_samples_per_pixel(SPP)
@@ -149,10 +166,11 @@ def main():
                        "parallelism": "frame-index split x%d + RCCL sum all-reduce" % world if distributed else "1 GPU",
                        "samples_per_step": samples_per_rank_step * world},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": load_measured_traffic(),
                          "kernel_ms": avg_kernel_s * 1e3, "flops_per_sample": flops_per_sample,
-                         "note": "FP32 VALU-bound kernel (no MFMA, negligible HBM traffic: 36 B per pixel per "
-                                 "launch); achieved = algorithmic FLOP per launch / HIP-event kernel time"},
+                         "note": "FP32 VALU-bound kernel (no MFMA; HBM traffic is the 16 B per-frame sum per pixel "
+                                 "per frame, ~2.1 GB per launch, i.e. ~50 GB/s); achieved = algorithmic FLOP per launch / "
+                                 "HIP-event kernel time; traffic = bytes per launch from the committed rocprofv3 PMC passes"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pkg)

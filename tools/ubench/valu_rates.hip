@@ -82,6 +82,33 @@ DEFINE_PK_KERNEL(pk_add_f32, "v_pk_add_f32 %0, %0, %1")
 DEFINE_PK_KERNEL(pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
 DEFINE_PK_KERNEL(pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
 
+// exec-mask experiments: does a half-empty wave issue faster?
+#define DEFINE_MASKED_KERNEL(NAME, COND)                                                       \
+    __global__ __launch_bounds__(256) void k_##NAME(float* out, int iters, float seed)          \
+    {                                                                                          \
+        float r[8];                                                                            \
+        for (int i = 0; i < 8; ++i) r[i] = seed + threadIdx.x * 1e-3f + i;                     \
+        float a = seed * 0.5f + 1.0f;                                                          \
+        const unsigned lane = threadIdx.x & 63u;                                               \
+        if (COND) {                                                                            \
+            for (int it = 0; it < iters; ++it) {                                               \
+                _Pragma("unroll") for (int u = 0; u < kUnroll / 8; ++u) {                      \
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                            \
+                        asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(a));            \
+                    }                                                                          \
+                }                                                                              \
+            }                                                                                  \
+        }                                                                                      \
+        float s = 0;                                                                           \
+        for (int i = 0; i < 8; ++i) s += r[i];                                                 \
+        if (s == 12345.678f) out[0] = s;                                                       \
+    }
+DEFINE_MASKED_KERNEL(add_low32, lane < 32u)
+DEFINE_MASKED_KERNEL(add_high32, lane >= 32u)
+DEFINE_MASKED_KERNEL(add_even, (lane & 1u) == 0u)
+DEFINE_MASKED_KERNEL(add_one_lane, lane == 5u)
+DEFINE_MASKED_KERNEL(add_low16, lane < 16u)
+
 // dependent chain (latency-bound): one register
 __global__ __launch_bounds__(256) void k_dep_add(float* out, int iters, float seed)
 {
@@ -139,7 +166,7 @@ int main()
     CHECK(hipMalloc(&out, 4));
     std::vector<Entry> entries = {
 #define E(n) { #n, k_##n }
-        E(add_f32), E(mul_f32), E(fma_f32), E(pk_add_f32), E(pk_mul_f32), E(pk_fma_f32), E(mul_lo_u32), E(mul_hi_u32),
+        E(add_f32), E(add_low32), E(add_high32), E(add_even), E(add_one_lane), E(add_low16), E(mul_f32), E(fma_f32), E(pk_add_f32), E(pk_mul_f32), E(pk_fma_f32), E(mul_lo_u32), E(mul_hi_u32),
         E(mul_u32_u24), E(mad_u32_u24), E(mad_u64_u32), E(add_u32), E(and_b32), E(xor3), E(lshl_add_u32), E(bfe_i32),
         E(cvt_f32_u32), E(cvt_u32_f32), E(rcp_f32), E(sqrt_f32), E(rsq_f32), E(div_scale), E(div_fmas), E(div_fixup),
         E(cndmask), E(cmp_lt), E(floor_f32), E(ldexp_f32), E(max_f32), E(mov), E(dep_add), E(dep_rcp), E(ds_read_b128_bcast),

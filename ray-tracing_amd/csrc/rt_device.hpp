@@ -272,37 +272,55 @@ __device__ __forceinline__ float root_div(float n, const RayDenominator& rd)
     return q;
 }
 
-// The root-finding half of hitSphere, raytrace.comp.glsl:111-133.  geom = (centre, radius^2).
-// Returns true and the accepted root when the sphere is hit inside [tmin, tmax]; tmin must be > 0.
-template <class Stats>
-__device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, const RayDenominator& rden, float tmin, float tmax,
-                                            float& root_out, Stats& st)
+// hitSphere up to the discriminant, raytrace.comp.glsl:111-115.  geom = (centre, radius^2).
+struct SphereQuadratic {
+    float half_b;
+    float c;
+    float discriminant;
+};
+__device__ __forceinline__ SphereQuadratic sphere_quadratic(float4 geom, f3 o, f3 d, float a)
 {
+    SphereQuadratic q;
     f3 oc = o - mk(geom.x, geom.y, geom.z);
-    float half_b = dot(oc, d);
-    float c = dot(oc, oc) - geom.w;
-    float discriminant = half_b * half_b - rden.a * c;
-    if (discriminant < 0.0f) {
+    q.half_b = dot(oc, d);
+    q.c = dot(oc, oc) - geom.w;
+    q.discriminant = q.half_b * q.half_b - a * q.c;
+    return q;
+}
+// hitSphere from the discriminant test to the accepted root, :117-133.  Returns true and the
+// accepted root when the sphere is hit inside [tmin, tmax]; tmin must be > 0.
+template <class Stats>
+__device__ __forceinline__ bool sphere_root_from(const SphereQuadratic& q, const RayDenominator& rden, float tmin, float tmax,
+                                                 float& root_out, Stats& st)
+{
+    if (q.discriminant < 0.0f) {
         return false;
     }
     // Origin outside the sphere and moving away from it (half_b > 0, c > 0, both below 2^59, a
     // positive and finite): sqrt_disc <= half_b, so both roots are <= 0 < tmin and :125-131 reject
     // them.  Positive floats order like their bit patterns, so one unsigned compare tests both.
-    if (rden.a_ok && (__float_as_uint(half_b) | __float_as_uint(c)) < 0x5D000000u) {
+    if (rden.a_ok && (__float_as_uint(q.half_b) | __float_as_uint(q.c)) < 0x5D000000u) {
         return false;
     }
     st.section(5 /* ST_ROOT */);
-    float sqrt_disc = sqrt_exact(discriminant);
-    float root = root_div(-half_b - sqrt_disc, rden);
+    float sqrt_disc = sqrt_exact(q.discriminant);
+    float root = root_div(-q.half_b - sqrt_disc, rden);
     if (root < tmin || root > tmax) {
         st.section(6 /* ST_FAR_ROOT */);
-        root = root_div(-half_b + sqrt_disc, rden);
+        root = root_div(-q.half_b + sqrt_disc, rden);
         if (root < tmin || root > tmax) {
             return false;
         }
     }
     root_out = root;
     return true;
+}
+// The root-finding half of hitSphere, raytrace.comp.glsl:111-133.
+template <class Stats>
+__device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, const RayDenominator& rden, float tmin, float tmax,
+                                            float& root_out, Stats& st)
+{
+    return sphere_root_from(sphere_quadratic(geom, o, d, rden.a), rden, tmin, tmax, root_out, st);
 }
 
 // The record-filling half of hitSphere, raytrace.comp.glsl:135-143.

@@ -42,7 +42,6 @@ namespace {
 #define RT_SGPR_ATTR
 #endif
 constexpr int kBlockThreads = 256;
-constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr float kTMin = 0.001f;
 
 // ---- diagnostic section counters -------------------------------------------------------------
@@ -127,7 +126,7 @@ template <bool MAT_IN_LDS>
 __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ spheres, uint32_t count,
                                             float4* geom, float4* mat0, float4* mat1)
 {
-    for (uint32_t i = threadIdx.x; i < count; i += kBlockThreads) {
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
         const float4* src = reinterpret_cast<const float4*>(spheres + i);
         float4 cr = src[0];
         geom[i] = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
@@ -146,8 +145,10 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <bool MAT_IN_LDS, class Stats>
-__global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
+// BLOCK = threads per workgroup: 256 for scenes whose whole records fit in LDS, 512 for the
+// geometry-only layout (64 KiB of LDS per workgroup: two workgroups, 16 waves, per CU).
+template <bool MAT_IN_LDS, class Stats, int BLOCK>
+__global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
     extern __shared__ float4 lds[];
     const uint32_t sphere_count = A.params.frame_sample_depth_count[3];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
     Stats st;
 
     // ---- this wave's unit: (tile, frame chunk), chunk-major ----
-    const uint32_t unit = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t unit = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (unit >= A.n_tiles * A.n_chunks) {
         return;
     }
@@ -227,15 +228,43 @@ __global__ __launch_bounds__(kBlockThreads, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void
         rden.a_ok = true;
         if (live) {
             rden = ray_denominator(rd);
-            for (uint32_t i = 0; i < sphere_count; ++i) {
+            uint32_t i = 0;
+            if (!MAT_IN_LDS) {
+                // Large scenes: four records per trip, fetched together so that one LDS wait covers
+                // them and the four discriminants overlap; the roots are still resolved in index
+                // order (an equal-t later sphere replaces an earlier one, :125 with tMax = closest).
+                for (; i + 4u <= sphere_count; i += 4u) {
+                    const float4 g0 = geom[i], g1 = geom[i + 1u], g2 = geom[i + 2u], g3 = geom[i + 3u];
+                    const SphereQuadratic q0 = sphere_quadratic(g0, ro, rd, rden.a);
+                    const SphereQuadratic q1 = sphere_quadratic(g1, ro, rd, rden.a);
+                    const SphereQuadratic q2 = sphere_quadratic(g2, ro, rd, rden.a);
+                    const SphereQuadratic q3 = sphere_quadratic(g3, ro, rd, rden.a);
+                    // one branch per four spheres: almost always all four discriminants are negative
+                    if (!(q0.discriminant < 0.0f) || !(q1.discriminant < 0.0f) || !(q2.discriminant < 0.0f) ||
+                        !(q3.discriminant < 0.0f)) {
+                        float root;
+                        if (sphere_root_from(q0, rden, kTMin, closest, root, st)) {
+                            closest = root;
+                            best = (int)i;
+                        }
+                        if (sphere_root_from(q1, rden, kTMin, closest, root, st)) {
+                            closest = root;
+                            best = (int)i + 1;
+                        }
+                        if (sphere_root_from(q2, rden, kTMin, closest, root, st)) {
+                            closest = root;
+                            best = (int)i + 2;
+                        }
+                        if (sphere_root_from(q3, rden, kTMin, closest, root, st)) {
+                            closest = root;
+                            best = (int)i + 3;
+                        }
+                    }
+                }
+            }
+            for (; i < sphere_count; ++i) {
                 float root;
-#ifdef RT_GEOM_SCALAR
-                const float4 cr = reinterpret_cast<const float4*>(A.spheres)[3u * i];
-                const float4 gi = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
-#else
-                const float4 gi = geom[i];
-#endif
-                if (sphere_root(gi, ro, rd, rden, kTMin, closest, root, st)) {
+                if (sphere_root(geom[i], ro, rd, rden, kTMin, closest, root, st)) {
                     closest = root;
                     best = (int)i;
                 }
@@ -606,8 +635,7 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     args.frames_per_unit = args.frames_per_unit > 64u ? 64u : args.frames_per_unit;
     args.n_chunks = (args.n_frames + args.frames_per_unit - 1) / args.frames_per_unit;
     const uint64_t units = tiles * args.n_chunks;
-    const uint64_t blocks = (units + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (units > 0xFFFFFFFFull || blocks > 0x7FFFFFFFull) {
+    if (units > 0xFFFFFFFFull) {
         return hipErrorInvalidValue;
     }
     args.n_tiles = (uint32_t)tiles;
@@ -616,19 +644,22 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     }
     bool full = false;
     const size_t lds = trace_lds_bytes(args.params.frame_sample_depth_count[3], &full);
+    const uint32_t block_threads = full ? 256u : 512u;
+    const uint32_t waves_per_block = block_threads / 64u;
+    const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
+    if (blocks > 0x7FFFFFFFull) {
+        return hipErrorInvalidValue;
+    }
 #ifdef RT_STATS
-    if (full) {
-        hipLaunchKernelGGL((rt_trace_kernel<true, WaveStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
-    } else {
-        hipLaunchKernelGGL((rt_trace_kernel<false, WaveStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
-    }
+    typedef WaveStats StatsPolicy;
 #else
-    if (full) {
-        hipLaunchKernelGGL((rt_trace_kernel<true, NoStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
-    } else {
-        hipLaunchKernelGGL((rt_trace_kernel<false, NoStats>), dim3((uint32_t)blocks), dim3(kBlockThreads), lds, stream, args);
-    }
+    typedef NoStats StatsPolicy;
 #endif
+    if (full) {
+        hipLaunchKernelGGL((rt_trace_kernel<true, StatsPolicy, 256>), dim3((uint32_t)blocks), dim3(256), lds, stream, args);
+    } else {
+        hipLaunchKernelGGL((rt_trace_kernel<false, StatsPolicy, 512>), dim3((uint32_t)blocks), dim3(512), lds, stream, args);
+    }
     return hipGetLastError();
 }
 

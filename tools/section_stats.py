@@ -28,10 +28,15 @@ def main():
     lib.rt_debug_read_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     n = lib.rt_debug_stats_sections()
     assert n == len(SECTIONS), (n, len(SECTIONS))
-    t = pkg.RayTracer().create(1920, 1080, device_id=0)
+    big = os.environ.get("RT_STATS_SCENE") == "synthetic4096"
+    width, height = (960, 540) if big else (1920, 1080)
+    t = pkg.RayTracer().create(width, height, device_id=0)
     t.set_samples_per_pixel(16)
-    t.set_max_depth(8)
-    t.set_aperture(0.0)
+    t.set_max_depth(50 if big else 8)
+    t.set_aperture(0.05 if big else 0.0)
+    if big:
+        t.set_spheres(pkg.synthetic_scene(4096))
+        t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
     lib.rt_debug_stats_phases.restype = ctypes.c_int
     nph = lib.rt_debug_stats_phases()
     buf = (ctypes.c_uint64 * (2 * n + nph))()
@@ -39,7 +44,7 @@ def main():
     t.render_frames(0, frames)
     t.synchronize()
     assert lib.rt_debug_read_stats(t.handle, buf, 0) == 0
-    samples = 1920 * 1080 * 16 * frames
+    samples = width * height * 16 * frames
     iters = buf[0]
     out = {}
     print("%-10s %14s %10s %12s %10s" % ("section", "wave execs", "per iter", "mean lanes", "lanes/64"))
@@ -55,7 +60,7 @@ def main():
     for name, c in zip(phases, cyc):
         print("  %-20s %6.1f %%   %8.1f cycles/iteration" % (name, 100.0 * c / tot, c / iters))
     out["_phases"] = dict(zip(phases, [int(c) for c in cyc]))
-    print("wave iterations per wave-sample: %.3f (ideal = segments/sample = 1.946)" % (iters / (samples / 64.0)))
+    print("wave iterations per wave-sample: %.3f (ideal = segments per sample: 1.946 for the default scene)" % (iters / (samples / 64.0)))
     json.dump({"frames": frames, "samples": samples, "sections": out}, open(os.path.join(ROOT, "gpurun_out", "section_stats.json"), "w"), indent=1)
     t.destroy()
 

@@ -155,15 +155,16 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     float4* geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
-    stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1);
+    // per-wave tables of the three hash terms of :37-44 for this unit's columns, rows and frames
+    // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
+    uint32_t* hash_tab = reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 3u : 1u) * sphere_count) + (threadIdx.x >> 6) * 80u;
 
     Stats st;
 
     // ---- this wave's unit: (tile, frame chunk), chunk-major ----
-    const uint32_t unit = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (unit >= A.n_tiles * A.n_chunks) {
-        return;
-    }
+    const uint32_t n_units = A.n_tiles * A.n_chunks;
+    const uint32_t unit = min(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), n_units - 1u);
+    const bool spare_wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6) >= n_units;
     const uint32_t chunk = unit / A.n_tiles;
     const uint32_t tile = unit - chunk * A.n_tiles;
     const uint32_t tile_y = tile / A.tiles_x;
@@ -177,6 +178,19 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t rel_count = min(A.frames_per_unit, A.n_frames - rel_begin);
     const uint32_t n_items = tile_pixels * rel_count;
     uint32_t next_item = 0; // wave-uniform pool cursor
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane < 16u) {
+            hash_tab[lane] = hash1(lane < 8u ? x0 + lane : y0 + lane - 8u);
+        }
+        if (lane < rel_count) {
+            hash_tab[16u + lane] = hash1(A.first_frame + (rel_begin + lane) * A.frame_stride);
+        }
+    }
+    stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1); // ends with the workgroup barrier
+    if (spare_wave) {
+        return; // the last workgroup may have more waves than units are left
+    }
 
     const uint32_t spp_raw = A.params.frame_sample_depth_count[1];
     const uint32_t spp = spp_raw > 1u ? spp_raw : 1u; // :308
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             texel = py * A.width + px;
             fpx = (float)(int32_t)px;
             fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
-            rng = hash3(px, py, A.first_frame + rel * A.frame_stride); // :310-311
+            rng = hash_tab[lx] ^ hash_tab[8u + ly] ^ hash_tab[16u + frame_in_chunk]; // :310-311
             samples_left = spp;
             has_item = true;
         }
@@ -616,7 +630,8 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
     if (mat_in_lds != nullptr) {
         *mat_in_lds = full;
     }
-    return (size_t)sphere_count * (full ? 48u : 16u);
+    // scene records + 80 hash words for each of up to 8 waves
+    return (size_t)sphere_count * (full ? 48u : 16u) + 8u * 80u * 4u;
 }
 
 hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)

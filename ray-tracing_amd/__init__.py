@@ -5,7 +5,8 @@ The directory name carries a hyphen, so import it through rtamd_loader.load()
 """
 from .tracer import (ABI, GPUParams, GPUSphere, LIB_PATH, RayTracer, load_library, probe_arith, probe_hit_sphere,
                      probe_pow, probe_rng)
-from .scene import default_scene, synthetic_scene
+from .scene import default_scene, load_scene, random_scene, save_scene, synthetic_scene
+from .caller import FrameLoop
 
 __all__ = ["ABI", "GPUParams", "GPUSphere", "LIB_PATH", "RayTracer", "load_library", "probe_hit_sphere",
-           "probe_pow", "probe_rng", "probe_arith", "default_scene", "synthetic_scene"]
+           "probe_pow", "probe_rng", "probe_arith", "default_scene", "synthetic_scene", "random_scene", "load_scene", "save_scene", "FrameLoop"]

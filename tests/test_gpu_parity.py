@@ -340,3 +340,50 @@ def test_converged_radiance_properties(pkg, oracle):
     mean_ref = ref["accum"][..., :3].mean() / 256.0
     assert abs(mean_gpu - mean_ref) <= 0.02 * mean_ref
     t.destroy()
+
+
+def _replay(pkg, oracle, script, w, h):
+    t = pkg.RayTracer().create(w, h, device_id=0)
+
+    class Tap:
+        """Intercepts render() to run the oracle with the uniform block of that very dispatch."""
+
+        def __init__(self):
+            self.accum = np.zeros((h, w, 4), dtype=np.float32)
+            self.flag = True      # rt_create raises the reset flag
+            self.out = None
+
+        def render(self, frame):
+            if self.flag or frame == 0:
+                self.accum[...] = 0.0
+            self.flag = False
+            self.out = oracle.render(t.get_params_words(frame), pkg.default_scene(), accum=self.accum)
+            t.render(frame)
+
+        def __getattr__(self, name):
+            attr = getattr(t, name)
+            if name.startswith("set_") or name == "resize":
+                def wrapped(*a, **k):
+                    if name != "set_focus_distance" or a[0] > 0:
+                        self.flag = True
+                    return attr(*a, **k)
+                return wrapped
+            return attr
+
+    tap = Tap()
+    loop = pkg.FrameLoop(tap)
+    tap.set_max_depth(6)
+    for ev in script:
+        loop.step(**ev)
+    got_acc, got_out = t.read_accum(), t.read_output()
+    t.destroy()
+    return loop, tap, got_acc, got_out
+
+
+def test_frame_loop_replay_matches_oracle(pkg, oracle):
+    script = [dict(), dict(), dict(mouse=(25.0, 5.0)), dict(), dict(sliders={"samples": 2}), dict(),
+              dict(keys={"W", "D"}, dt=0.1), dict(), dict(sliders={"aperture": 0.0}), dict(), dict()]
+    loop, tap, got_acc, got_out = _replay(pkg, oracle, script, 72, 40)
+    assert loop.rendered == [0, 1, 0, 1, 2, 1, 0, 1, 2, 1, 2]
+    assert same(got_acc, tap.accum)
+    assert same(got_out, tap.out["output"])

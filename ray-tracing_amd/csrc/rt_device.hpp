@@ -79,14 +79,20 @@ __device__ __forceinline__ float div_shared(float n, float d, float r, bool d_ok
 // whose residual changes sign), full sequence otherwise.
 __device__ __forceinline__ float sqrt_core(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
-    float s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    float r_dn = __builtin_fmaf(-s_dn, s, x);
-    float r_up = __builtin_fmaf(-s_up, s, x);
-    s = (r_dn <= 0.0f) ? s_dn : s;
-    s = (r_up > 0.0f) ? s_up : s;
-    return s;
+    // s is within one ulp of sqrt(x).  With s_dn / s_up its neighbours, the correctly rounded root is
+    // s_dn if x - s_dn*s <= 0, s_up if x - s_up*s > 0, else s (the two cannot hold together).  The
+    // residuals are formed with the opposite sign, e_dn = s_dn*s - x and e_up = s_up*s - x (exact
+    // zeros come out as +0), so each condition is one sign bit: e_dn >= 0 and e_up < 0.
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const uint32_t s_dn_bits = __float_as_uint(s) - 1u;
+    const float s_dn = __uint_as_float(s_dn_bits);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_dn = __builtin_fmaf(s_dn, s, -x);
+    const float e_up = __builtin_fmaf(s_up, s, -x);
+    const int32_t keep = ((int32_t)__float_as_uint(e_dn)) >> 31; // -1: e_dn < 0, stay at s;  0: step down
+    const int32_t up = ((int32_t)__float_as_uint(e_up)) >> 31;   // -1: e_up < 0, step up;    0: stay
+    // s_dn_bits + (keep ? 1 : 0) + (up ? 1 : 0)
+    return __uint_as_float(s_dn_bits - (uint32_t)keep - (uint32_t)up);
 }
 __device__ __forceinline__ float sqrt_exact(float x)
 {

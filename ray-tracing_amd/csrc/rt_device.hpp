@@ -321,6 +321,33 @@ __device__ __forceinline__ bool sphere_root_from(const SphereQuadratic& q, const
     root_out = root;
     return true;
 }
+// The same, folding the caller's bookkeeping of :254-258 (closest = t, best = this sphere) into the
+// accepting paths, so that a sphere nobody hits costs no select instructions.
+template <class Stats>
+__device__ __forceinline__ void sphere_closest(const SphereQuadratic& q, const RayDenominator& rden, float tmin, int index,
+                                               float& closest, int& best, Stats& st)
+{
+    if (q.discriminant < 0.0f) {
+        return;
+    }
+    if (rden.a_ok && (__float_as_uint(q.half_b) | __float_as_uint(q.c)) < 0x5D000000u) {
+        return; // outside and moving away: both roots <= 0 < tmin (see sphere_root_from)
+    }
+    st.section(5 /* ST_ROOT */);
+    const float sqrt_disc = sqrt_exact(q.discriminant);
+    const float near_root = root_div(-q.half_b - sqrt_disc, rden);
+    if (near_root < tmin || near_root > closest) {
+        st.section(6 /* ST_FAR_ROOT */);
+        const float far_root = root_div(-q.half_b + sqrt_disc, rden);
+        if (!(far_root < tmin || far_root > closest)) {
+            closest = far_root;
+            best = index;
+        }
+    } else {
+        closest = near_root;
+        best = index;
+    }
+}
 // The root-finding half of hitSphere, raytrace.comp.glsl:111-133.
 template <class Stats>
 __device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, const RayDenominator& rden, float tmin, float tmax,

@@ -277,11 +277,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 }
             }
             for (; i < sphere_count; ++i) {
-                float root;
-                if (sphere_root(geom[i], ro, rd, rden, kTMin, closest, root, st)) {
-                    closest = root;
-                    best = (int)i;
-                }
+                sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
             }
         }
         st.phase_end(PH_INTERSECT);

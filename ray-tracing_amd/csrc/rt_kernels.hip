@@ -285,10 +285,10 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         const bool miss = live && !hit;
 
         // ------------------------------------------------------------------ winner's record, :135-149
-        f3 p = ro, n = ro, albedo = ro;
+        f3 p, n, albedo; // defined for hit lanes only
         bool front = false;
         uint32_t mat = 3u;
-        float fuzz = 0.0f, ref_idx = 1.0f, flags = 0.0f;
+        float fuzz, ref_idx, flags;
         if (hit) {
             st.section(ST_HIT);
             const float4 g = geom[best];

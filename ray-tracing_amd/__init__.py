@@ -7,6 +7,7 @@ from .tracer import (ABI, GPUParams, GPUSphere, LIB_PATH, RayTracer, load_librar
                      probe_pow, probe_rng)
 from .scene import default_scene, load_scene, random_scene, save_scene, synthetic_scene
 from .caller import FrameLoop
+from . import image
 
 __all__ = ["ABI", "GPUParams", "GPUSphere", "LIB_PATH", "RayTracer", "load_library", "probe_hit_sphere",
-           "probe_pow", "probe_rng", "probe_arith", "default_scene", "synthetic_scene", "random_scene", "load_scene", "save_scene", "FrameLoop"]
+           "probe_pow", "probe_rng", "probe_arith", "default_scene", "synthetic_scene", "random_scene", "load_scene", "save_scene", "FrameLoop", "image"]

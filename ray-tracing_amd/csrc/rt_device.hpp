@@ -41,6 +41,11 @@ __device__ __forceinline__ float glsl_max(float x, float y) { return (x < y) ? y
 // the compiler keeps them behind a branch that is skipped when no lane needs them, instead of
 // computing both variants and selecting.
 #define RT_COLD_PATH() asm volatile("; full-range sequence" ::)
+// The same device for short blocks that only assign: behind a real branch the assignments are
+// v_mov under the branch's exec mask.  If-converted they become v_cndmask_b32 reading a VCC that a
+// scalar instruction combined, and on gfx950 such a select costs about ten times a v_mov (the VOP2
+// select is only cheap right behind the vector compare that wrote VCC).
+#define RT_KEEP_BRANCH() asm volatile("; assignments under exec" ::)
 constexpr float kDenLo = 0x1p-20f;  // denominators in [2^-20, 2^20]
 constexpr float kDenHi = 0x1p20f;
 constexpr float kNumLo = 0x1p-90f;  // numerators with 2^-90 <= |n| < 2^100
@@ -340,6 +345,7 @@ __device__ __forceinline__ void sphere_closest(const SphereQuadratic& q, const R
         st.section(6 /* ST_FAR_ROOT */);
         const float far_root = root_div(-q.half_b + sqrt_disc, rden);
         if (!(far_root < tmin || far_root > closest)) {
+            RT_KEEP_BRANCH();
             closest = far_root;
             best = index;
         }

@@ -383,10 +383,13 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         float mx = 0.0f, my = 0.0f, mz = 0.0f, m_dot = 0.0f;
         if (gen || want3) {
             st.section(ST_RIS);
-            const uint32_t mul3 = want3 ? 1664525u : 1u;
-            const uint32_t add3 = want3 ? 1013904223u : 0u;
-            const uint32_t mask3 = want3 ? 0x00FFFFFFu : 0u;
-            const int32_t off3 = want3 ? 0x00800000 : 0;
+            // Per-lane third draw without selects: all-ones for the lambert/metal lanes (mat 0 or 1;
+            // dielectric is 2 and lanes without a hit carry 3), zero for the camera lanes.
+            const uint32_t is3 = (uint32_t)((int32_t)(mat - 2u) >> 31);
+            const uint32_t mul3 = (is3 & (1664525u - 1u)) + 1u;
+            const uint32_t add3 = is3 & 1013904223u;
+            const uint32_t mask3 = is3 & 0x00FFFFFFu;
+            const int32_t off3 = (int32_t)(is3 & 0x00800000u);
             do {
                 st.section(ST_RIS_IT);
                 const uint32_t s1 = 1664525u * rng + 1013904223u;

@@ -98,6 +98,23 @@ int rt_set_spheres(rt_handle h, const rt_gpu_sphere *spheres, uint32_t n);
 /* Copies out up to cap spheres of the current scene; *n receives the count. */
 int rt_get_spheres(rt_handle h, rt_gpu_sphere *out, uint32_t cap, uint32_t *n);
 
+/* Scenes of 64 spheres or more are traced through a bounding-sphere hierarchy
+ * that rt_set_spheres builds: a ray is only tested against the spheres whose
+ * enclosing balls it can reach, each with the arithmetic of hitSphere
+ * (shaders/raytrace.comp.glsl:109-133), and the closest-hit rule of :247-259 is
+ * kept (smallest root, the higher index on an exact tie), so images are
+ * bit-identical to testing every sphere.  The reference has no counterpart (its
+ * loop visits all spheres).  enable = 0 goes back to that loop; the default is 1.
+ * Does not raise the reset flag. */
+int rt_set_scene_hierarchy(rt_handle h, int enable);
+/* Copies out up to cap nodes of the hierarchy of the current scene, in
+ * depth-first order: geom receives 4 floats per node (centre; radius^2 for a
+ * leaf, 1.125 R^2 for an inner node), word one 32-bit value per node (bit 31
+ * leaf, bits 17..30 sphere index of a leaf, bits 0..16 byte offset = 16 * index
+ * of the node to continue with when the node's test fails).  *n_nodes receives
+ * the node count, 0 when the scene has no hierarchy.  Either array may be NULL. */
+int rt_get_scene_hierarchy(rt_handle h, float *geom, uint32_t *word, uint32_t cap, uint32_t *n_nodes);
+
 /* RayTracer::makeCameraParams + updateParams, src/rt/RayTracer.cpp:140-177,
  * :550-557: the 160-byte block a dispatch for frame_index would receive. */
 int rt_get_params(rt_handle h, uint32_t frame_index, rt_gpu_params *out);

@@ -261,6 +261,10 @@ struct RayDenominator {
     float a;
     float rcp_a;
     bool a_ok;
+    // a_ok, the origin below 2^30 in magnitude and every sphere within the bounded range
+    // (|centre| <= 2^20, radius^2 <= 2^40, all finite): half_b, c and the discriminant of every
+    // sphere are then finite and far from overflow, which the sign test of behind_origin() needs
+    bool bounded;
 };
 __device__ __forceinline__ RayDenominator ray_denominator(f3 d)
 {
@@ -268,7 +272,28 @@ __device__ __forceinline__ RayDenominator ray_denominator(f3 d)
     r.a = dot(d, d);
     r.rcp_a = refined_rcp(r.a);
     r.a_ok = den_in_range(r.a);
+    r.bounded = false;
     return r;
+}
+__device__ __forceinline__ RayDenominator ray_denominator(f3 o, f3 d, bool scene_bounded)
+{
+    RayDenominator r = ray_denominator(d);
+    r.bounded = scene_bounded && r.a_ok && (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z) < 0x1p30f;
+    return r;
+}
+// Whether the centre of a sphere (or of a ball) is behind the origin of a ray that starts outside
+// it: half_b >= 0 and c >= 0, i.e. neither sign bit is set.  With a non-negative discriminant this
+// gives sqrt(disc) <= half_b (disc <= fl(half_b^2) because a*c >= 0, and the correctly rounded
+// square root of fl(x*x) is x), so both roots are <= 0, apart from a positive far root below 2^-43
+// when half_b^2 underflows; either way they are below tmin > 0 and :125-131 reject them.
+__device__ __forceinline__ bool behind_origin(float half_b, float c)
+{
+    return (int32_t)(__float_as_uint(half_b) | __float_as_uint(c)) >= 0;
+}
+__device__ __forceinline__ bool sphere_bounded(float4 centre_radius)
+{
+    return fabsf(centre_radius.x) <= 0x1p20f && fabsf(centre_radius.y) <= 0x1p20f && fabsf(centre_radius.z) <= 0x1p20f &&
+           fabsf(centre_radius.w) <= 0x1p20f;
 }
 // (-half_b -/+ sqrt_disc) / a, :123 and :127.  A numerator below 2^-90 in magnitude gives a root
 // far below tmin = 0.001 whichever way it is rounded, and such a root is rejected and never
@@ -298,6 +323,17 @@ __device__ __forceinline__ SphereQuadratic sphere_quadratic(float4 geom, f3 o, f
     q.discriminant = q.half_b * q.half_b - a * q.c;
     return q;
 }
+// The same with dot(oc,oc) multiplied by `scale` first: scale = 1 reproduces sphere_quadratic bit
+// for bit (x * 1.0f is x), a scale slightly below 1 is the conservative test of a bounding sphere.
+__device__ __forceinline__ SphereQuadratic sphere_quadratic_scaled(float4 geom, f3 o, f3 d, float a, float scale)
+{
+    SphereQuadratic q;
+    f3 oc = o - mk(geom.x, geom.y, geom.z);
+    q.half_b = dot(oc, d);
+    q.c = dot(oc, oc) * scale - geom.w;
+    q.discriminant = q.half_b * q.half_b - a * q.c;
+    return q;
+}
 // hitSphere from the discriminant test to the accepted root, :117-133.  Returns true and the
 // accepted root when the sphere is hit inside [tmin, tmax]; tmin must be > 0.
 template <class Stats>
@@ -307,10 +343,8 @@ __device__ __forceinline__ bool sphere_root_from(const SphereQuadratic& q, const
     if (q.discriminant < 0.0f) {
         return false;
     }
-    // Origin outside the sphere and moving away from it (half_b > 0, c > 0, both below 2^59, a
-    // positive and finite): sqrt_disc <= half_b, so both roots are <= 0 < tmin and :125-131 reject
-    // them.  Positive floats order like their bit patterns, so one unsigned compare tests both.
-    if (rden.a_ok && (__float_as_uint(q.half_b) | __float_as_uint(q.c)) < 0x5D000000u) {
+    // origin outside the sphere and moving away from it: both roots are below tmin
+    if (rden.bounded && behind_origin(q.half_b, q.c)) {
         return false;
     }
     st.section(5 /* ST_ROOT */);
@@ -335,8 +369,8 @@ __device__ __forceinline__ void sphere_closest(const SphereQuadratic& q, const R
     if (q.discriminant < 0.0f) {
         return;
     }
-    if (rden.a_ok && (__float_as_uint(q.half_b) | __float_as_uint(q.c)) < 0x5D000000u) {
-        return; // outside and moving away: both roots <= 0 < tmin (see sphere_root_from)
+    if (rden.bounded && behind_origin(q.half_b, q.c)) {
+        return; // outside and moving away: both roots are below tmin
     }
     st.section(5 /* ST_ROOT */);
     const float sqrt_disc = sqrt_exact(q.discriminant);
@@ -351,6 +385,32 @@ __device__ __forceinline__ void sphere_closest(const SphereQuadratic& q, const R
         }
     } else {
         closest = near_root;
+        best = index;
+    }
+}
+// The same for spheres that are not visited in index order.  The loop of :247-259 ends with the
+// smallest accepted root and, among spheres whose roots are exactly equal, with the one tested
+// last, i.e. the highest index (a root equal to `closest` is not rejected by :125); both are
+// properties of the set of spheres, not of the order, so any order gives the loop's result once
+// ties go to the higher index.  The caller has already applied the discriminant and
+// behind-the-origin tests.
+template <class Stats>
+__device__ __forceinline__ void sphere_closest_any_order(const SphereQuadratic& q, const RayDenominator& rden, float tmin,
+                                                         int index, float& closest, int& best, Stats& st)
+{
+    st.section(5 /* ST_ROOT */);
+    const float sqrt_disc = sqrt_exact(q.discriminant);
+    float root = root_div(-q.half_b - sqrt_disc, rden);
+    if (root < tmin || root > closest) {
+        st.section(6 /* ST_FAR_ROOT */);
+        root = root_div(-q.half_b + sqrt_disc, rden);
+        if (root < tmin || root > closest) {
+            return;
+        }
+    }
+    if (root < closest || index > best) {
+        RT_KEEP_BRANCH();
+        closest = root;
         best = index;
     }
 }

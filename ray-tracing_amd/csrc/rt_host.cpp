@@ -22,6 +22,7 @@
 
 #include "../../include/rt_mi355x.h"
 #include "rt_kernels.hpp"
+#include "rt_tree.hpp"
 
 static_assert(sizeof(rt_gpu_sphere) == 48, "GPUSphere is 48 bytes (std430 stride)");
 static_assert(sizeof(rt_gpu_params) == 160, "GPUParams is 160 bytes (std140)");
@@ -43,6 +44,12 @@ struct rt_tracer {
     float4* partial = nullptr;        // per-frame sums of a multi-frame launch: [frames][height*width]
     size_t partial_bytes = 0;
     uint32_t* stats = nullptr;        // diagnostic builds only
+    rt::SphereTree tree;              // hierarchy over `spheres` (empty for small or out-of-range scenes)
+    bool use_tree = true;
+    bool scene_bounded = false;       // every sphere finite, |centre| and |radius| at most 2^20
+    float4* d_tree_geom = nullptr;
+    uint32_t* d_tree_word = nullptr;
+    uint32_t d_tree_capacity = 0;
 
     bool reset_accum = true;          // mResetAccum
     std::vector<rt_gpu_sphere> spheres; // mSpheres
@@ -243,6 +250,20 @@ int allocate_images(rt_tracer* h)
     return RT_OK;
 }
 
+// Hierarchy and range flag of the current sphere list (host side of a scene change).
+void index_scene(rt_tracer* h)
+{
+    h->scene_bounded = true;
+    for (const rt_gpu_sphere& s : h->spheres) {
+        for (int k = 0; k < 4; ++k) {
+            if (!(std::fabs(s.center_radius[k]) <= 0x1p20f)) { // also catches NaN
+                h->scene_bounded = false;
+            }
+        }
+    }
+    (void)rt::build_sphere_tree(h->spheres.data(), static_cast<uint32_t>(h->spheres.size()), h->tree); // empty when the scene does not qualify
+}
+
 // RayTracer::uploadScene, src/rt/RayTracer.cpp:529-548
 int upload_scene(rt_tracer* h, hipStream_t stream)
 {
@@ -258,8 +279,22 @@ int upload_scene(rt_tracer* h, hipStream_t stream)
         RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_spheres), n * sizeof(rt_gpu_sphere)));
         h->d_sphere_capacity = n;
     }
-    // pageable-memory copy: returns once the source has been staged, ordered on the stream
+    const uint32_t nodes = h->tree.node_count();
+    if (nodes > h->d_tree_capacity) {
+        RT_HIP_TRY(h, hipDeviceSynchronize());
+        if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); h->d_tree_geom = nullptr; }
+        if (h->d_tree_word) { (void)hipFree(h->d_tree_word); h->d_tree_word = nullptr; }
+        h->d_tree_capacity = 0;
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_geom), nodes * sizeof(float4)));
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_word), nodes * sizeof(uint32_t)));
+        h->d_tree_capacity = nodes;
+    }
+    // pageable-memory copies: each returns once the source has been staged, ordered on the stream
     RT_HIP_TRY(h, hipMemcpyAsync(h->d_spheres, h->spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice, stream));
+    if (nodes != 0) {
+        RT_HIP_TRY(h, hipMemcpyAsync(h->d_tree_geom, h->tree.geom.data(), nodes * sizeof(float4), hipMemcpyHostToDevice, stream));
+        RT_HIP_TRY(h, hipMemcpyAsync(h->d_tree_word, h->tree.word.data(), nodes * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    }
     RT_HIP_TRY(h, hipStreamSynchronize(stream));
     return RT_OK;
 }
@@ -268,6 +303,7 @@ int upload_scene(rt_tracer* h, hipStream_t stream)
 void init_default_state(rt_tracer* h)
 {
     build_default_scene(h->spheres);
+    index_scene(h);
     const V3 look_at = v3(0.0f, 1.0f, 0.0f);
     const V3 pos = v3(h->cam_pos[0], h->cam_pos[1], h->cam_pos[2]);
     const V3 d = look_at - pos;
@@ -366,6 +402,11 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.rng_out = (h->rng_capture && last_group) ? h->rng_state : nullptr;
         args.partial = count > 1 ? h->partial : nullptr;
         args.stats = h->stats;
+        const bool tree = h->use_tree && !h->tree.empty();
+        args.tree_geom = tree ? h->d_tree_geom : nullptr;
+        args.tree_word = tree ? h->d_tree_word : nullptr;
+        args.tree_nodes = tree ? h->tree.node_count() : 0u;
+        args.scene_bounded = h->scene_bounded ? 1u : 0u;
         args.width = h->width;
         args.height = h->height;
         args.row_begin = row_begin;
@@ -500,6 +541,8 @@ int rt_destroy(rt_handle h)
         (void)hipDeviceSynchronize(); // vkDeviceWaitIdle, :238
         free_images(h);
         if (h->d_spheres) { (void)hipFree(h->d_spheres); }
+        if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); }
+        if (h->d_tree_word) { (void)hipFree(h->d_tree_word); }
         for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
             if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }
@@ -589,6 +632,7 @@ int rt_set_spheres(rt_handle h, const rt_gpu_sphere* spheres, uint32_t n)
         return fail_arg(h, "more than 4096 spheres");
     }
     h->spheres.assign(spheres, spheres + n);
+    index_scene(h);
     h->reset_accum = true;
     if (h->device < 0) {
         return RT_OK;
@@ -609,6 +653,34 @@ int rt_get_spheres(rt_handle h, rt_gpu_sphere* out, uint32_t cap, uint32_t* n)
     }
     if (out != nullptr) {
         std::memcpy(out, h->spheres.data(), sizeof(rt_gpu_sphere) * std::min(cap, count));
+    }
+    return RT_OK;
+}
+
+int rt_set_scene_hierarchy(rt_handle h, int enable)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->use_tree = enable != 0;
+    return RT_OK;
+}
+
+int rt_get_scene_hierarchy(rt_handle h, float* geom, uint32_t* word, uint32_t cap, uint32_t* n_nodes)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    const uint32_t count = h->tree.node_count();
+    if (n_nodes != nullptr) {
+        *n_nodes = count;
+    }
+    const uint32_t take = std::min(cap, count);
+    if (geom != nullptr && take != 0) {
+        std::memcpy(geom, h->tree.geom.data(), sizeof(float) * 4 * take);
+    }
+    if (word != nullptr && take != 0) {
+        std::memcpy(word, h->tree.word.data(), sizeof(uint32_t) * take);
     }
     return RT_OK;
 }

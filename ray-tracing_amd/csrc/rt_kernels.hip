@@ -25,9 +25,14 @@
 // The sphere list is staged once per workgroup in LDS as (centre, radius^2) float4 records read at
 // a wave-uniform address (broadcast); material records are fetched only for the winning sphere.
 //
+// Scenes of kTreeMinSpheres spheres or more are traced through a bounding-sphere hierarchy
+// (rt_tree.hpp): each lane walks the depth-first node array on its own, one node per trip, and a
+// leaf goes through the same arithmetic as in the plain loop.
+//
 // Compile with -ffp-contract=off (see rt_device.hpp).
 #include "rt_device.hpp"
 #include "rt_kernels.hpp"
+#include "rt_tree.hpp"
 
 namespace rt {
 
@@ -121,6 +126,13 @@ struct WaveStats {
     }
 };
 
+// How the sphere list reaches the intersection loop.
+enum SceneMode {
+    kGeomLds = 0, // geometry records in LDS, material records read from memory for the winner
+    kFullLds = 1, // whole records in LDS
+    kTree = 2     // hierarchy nodes in LDS, sphere records read from memory for the winner
+};
+
 // Copies the scene into LDS: geometry always, material records when they fit.
 template <bool MAT_IN_LDS>
 __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ spheres, uint32_t count,
@@ -139,6 +151,17 @@ __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ sp
     __syncthreads();
 }
 
+// Copies the hierarchy into LDS.
+__device__ __forceinline__ void stage_tree(const float4* __restrict__ node_geom, const uint32_t* __restrict__ node_word,
+                                           uint32_t count, float4* geom, uint32_t* word)
+{
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        geom[i] = node_geom[i];
+        word[i] = node_word[i];
+    }
+    __syncthreads();
+}
+
 // Number of set bits of a wave mask below this lane.
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
 {
@@ -146,18 +169,26 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
 }
 
 // BLOCK = threads per workgroup: 256 for scenes whose whole records fit in LDS, 512 for the
-// geometry-only layout (64 KiB of LDS per workgroup: two workgroups, 16 waves, per CU).
-template <bool MAT_IN_LDS, class Stats, int BLOCK>
+// geometry-only layout (64 KiB of LDS per workgroup: two workgroups, 16 waves, per CU); the
+// hierarchy uses 256, 512 or 1024 depending on its size.
+template <int MODE, class Stats, int BLOCK>
 __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
+    constexpr bool MAT_IN_LDS = MODE == kFullLds;
     extern __shared__ float4 lds[];
     const uint32_t sphere_count = A.params.frame_sample_depth_count[3];
+    // records ahead of the hash tables: the scene (1 or 3 float4 per sphere) or the hierarchy
+    // (a float4 and a word per node)
+    const uint32_t lds_records = MODE == kTree ? A.tree_nodes : sphere_count;
     float4* geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
+    uint32_t* node_word = reinterpret_cast<uint32_t*>(lds + lds_records);
     // per-wave tables of the three hash terms of :37-44 for this unit's columns, rows and frames
     // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
-    uint32_t* hash_tab = reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 3u : 1u) * sphere_count) + (threadIdx.x >> 6) * 80u;
+    uint32_t* hash_tab = (MODE == kTree ? node_word + lds_records
+                                        : reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 3u : 1u) * sphere_count)) +
+                         (threadIdx.x >> 6) * 80u;
 
     Stats st;
 
@@ -187,7 +218,12 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             hash_tab[16u + lane] = hash1(A.first_frame + (rel_begin + lane) * A.frame_stride);
         }
     }
-    stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1); // ends with the workgroup barrier
+    // both end with the workgroup barrier
+    if (MODE == kTree) {
+        stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, geom, node_word);
+    } else {
+        stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1);
+    }
     if (spare_wave) {
         return; // the last workgroup may have more waves than units are left
     }
@@ -240,8 +276,39 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         rden.a = 1.0f;
         rden.rcp_a = 1.0f;
         rden.a_ok = true;
-        if (live) {
-            rden = ray_denominator(rd);
+        rden.bounded = false;
+        if (MODE == kTree) {
+            if (live) {
+                rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
+                // the skip tests of the hierarchy are proven for rays in the bounded range only
+                if (rden.bounded) {
+                    const uint32_t end = A.tree_nodes * 16u;
+                    uint32_t at = 0; // byte offset of this lane's node
+                    while (at < end) {
+                        const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + at);
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (at >> 2));
+                        // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
+                        const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
+                        const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, rden.a, k);
+                        uint32_t next = at + 16u;
+                        if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c)) {
+                            next = w & kTreeOffsetMask;
+                        } else if ((int32_t)w < 0) {
+                            sphere_closest_any_order(q, rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), closest, best, st);
+                        }
+                        at = next;
+                    }
+                } else {
+                    RT_COLD_PATH();
+                    for (uint32_t i = 0; i < sphere_count; ++i) {
+                        const float4 cr = *reinterpret_cast<const float4*>(A.spheres + i);
+                        const float4 g = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
+                        sphere_closest(sphere_quadratic(g, ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
+                    }
+                }
+            }
+        } else if (live) {
+            rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
             uint32_t i = 0;
             if (!MAT_IN_LDS) {
                 // Large scenes: four records per trip, fetched together so that one LDS wait covers
@@ -291,15 +358,16 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         float fuzz, ref_idx, flags;
         if (hit) {
             st.section(ST_HIT);
-            const float4 g = geom[best];
-            float4 m0, m1;
+            float4 g, m0, m1;
             if (MAT_IN_LDS) {
+                g = geom[best];
                 m0 = mat0[best];
                 m1 = mat1[best];
             } else {
                 const float4* src = reinterpret_cast<const float4*>(A.spheres + best);
                 const float4 cr = src[0];
                 const float4 al = src[1];
+                g = MODE == kTree ? cr : geom[best]; // only the centre is used
                 m0 = make_float4(al.x, al.y, al.z, cr.w);
                 m1 = src[2];
             }
@@ -560,7 +628,8 @@ __global__ void rt_probe_hit_kernel(const rt_gpu_sphere* spheres, const float* r
     float root = 0.0f;
     float* o8 = out + (size_t)i * 8;
     NoStats nost;
-    bool hit = sphere_root(geom, o, d, ray_denominator(d), tmin, tmax, root, nost);
+    bool hit = sphere_root(geom, o, d, ray_denominator(o, d, sphere_bounded(*reinterpret_cast<const float4*>(s.center_radius)) && tmin >= 1e-6f),
+                           tmin, tmax, root, nost);
     f3 p = mk(0, 0, 0), nn = mk(0, 0, 0);
     bool front = false;
     if (hit) {
@@ -633,6 +702,23 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
     return (size_t)sphere_count * (full ? 48u : 16u) + 8u * 80u * 4u;
 }
 
+namespace {
+
+template <int MODE, int BLOCK>
+void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStream_t stream)
+{
+#ifdef RT_STATS
+    typedef WaveStats StatsPolicy;
+#else
+    typedef NoStats StatsPolicy;
+#endif
+    const uint32_t waves_per_block = BLOCK / 64;
+    const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
+}
+
+} // namespace
+
 hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
 {
     TraceArgs args = args_in;
@@ -649,30 +735,35 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     args.frames_per_unit = args.frames_per_unit > 64u ? 64u : args.frames_per_unit;
     args.n_chunks = (args.n_frames + args.frames_per_unit - 1) / args.frames_per_unit;
     const uint64_t units = tiles * args.n_chunks;
-    if (units > 0xFFFFFFFFull) {
+    if (units > 0x7FFFFFFFull) {
         return hipErrorInvalidValue;
     }
     args.n_tiles = (uint32_t)tiles;
     if (args.n_frames > 1 && args.partial == nullptr) {
         return hipErrorInvalidValue; // several frames need the per-frame sum image
     }
+    if (args.tree_nodes != 0) {
+        if (args.tree_geom == nullptr || args.tree_word == nullptr || args.tree_nodes > kTreeMaxNodes) {
+            return hipErrorInvalidValue;
+        }
+        // a float4 and a word per node; the block size follows the footprint so that a CU's 160 KiB
+        // of LDS still hold 16 to 20 waves
+        const size_t nodes_bytes = (size_t)args.tree_nodes * 20u;
+        if (nodes_bytes <= 30u * 1024u) {
+            launch_trace_as<kTree, 256>(args, units, nodes_bytes + 4u * 80u * 4u, stream);
+        } else if (nodes_bytes <= 72u * 1024u) {
+            launch_trace_as<kTree, 512>(args, units, nodes_bytes + 8u * 80u * 4u, stream);
+        } else {
+            launch_trace_as<kTree, 1024>(args, units, nodes_bytes + 16u * 80u * 4u, stream);
+        }
+        return hipGetLastError();
+    }
     bool full = false;
     const size_t lds = trace_lds_bytes(args.params.frame_sample_depth_count[3], &full);
-    const uint32_t block_threads = full ? 256u : 512u;
-    const uint32_t waves_per_block = block_threads / 64u;
-    const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
-    if (blocks > 0x7FFFFFFFull) {
-        return hipErrorInvalidValue;
-    }
-#ifdef RT_STATS
-    typedef WaveStats StatsPolicy;
-#else
-    typedef NoStats StatsPolicy;
-#endif
     if (full) {
-        hipLaunchKernelGGL((rt_trace_kernel<true, StatsPolicy, 256>), dim3((uint32_t)blocks), dim3(256), lds, stream, args);
+        launch_trace_as<kFullLds, 256>(args, units, lds, stream);
     } else {
-        hipLaunchKernelGGL((rt_trace_kernel<false, StatsPolicy, 512>), dim3((uint32_t)blocks), dim3(512), lds, stream, args);
+        launch_trace_as<kGeomLds, 512>(args, units, lds, stream);
     }
     return hipGetLastError();
 }

@@ -27,6 +27,10 @@ struct TraceArgs {
     uint32_t* rng_out;            // optional per-pixel final RNG state
     float4* partial;              // [n_frames][height*width] per-frame sums; required when n_frames > 1
     uint32_t* stats;              // diagnostic builds only
+    const float4* tree_geom;      // hierarchy nodes (rt_tree.hpp), or nullptr
+    const uint32_t* tree_word;
+    uint32_t tree_nodes;          // 0 = test every sphere
+    uint32_t scene_bounded;       // every sphere finite with |centre| <= 2^20 and |radius| <= 2^20
     uint32_t width;
     uint32_t height;
     uint32_t row_begin;

@@ -1,0 +1,200 @@
+// Host-side construction of the bounding-sphere hierarchy described in rt_tree.hpp.
+//
+// Why the inflation makes skipping safe (u = 2^-24, the unit roundoff of binary32; all claims are
+// for rays whose dot(d,d) lies in [2^-20, 2^20] and whose origin is finite and below 2^30 in
+// magnitude -- the kernel sends every other ray through the plain loop):
+//
+//  * hitSphere computes disc = hb*hb - a*(dot(oc,oc) - r^2) with about ten roundings; its value
+//    differs from the exact a*(r^2 - q^2), q = distance of the centre from the ray's line, by
+//    less than 32u * a * |oc|^2.  A sphere can therefore only pass the discriminant test when
+//    q^2 < r^2 + 32u |oc|^2.
+//  * An internal node (centre C, all spheres below it inside the ball of radius R) is tested
+//    with the same expression, with w = 1.125 R^2 in place of r^2 and dot(oc,oc) scaled by
+//    k = 1 - 2^-13.  If that test fails in floating point, the exact distance Q of C from the line
+//    satisfies Q^2 >= 1.12 R^2 + 2020u |oc|^2, so s = Q - R obeys s^2 >= 216u |oc|^2
+//    (from (R+s)^2 <= 1.12 R^2 + 9.34 s^2).  Every sphere below the node then has q - r >= s and
+//    |oc_i| <= 2 |oc|, hence q^2 - r^2 >= s^2 >= 216u |oc|^2 > 32u |oc_i|^2: its discriminant is
+//    negative as computed, and the plain loop would have rejected it too.
+//  * A node whose ball lies behind the ray origin (origin outside the inflated ball, hb >= 0) is
+//    skipped as well: every sphere inside the ball meets the line only at parameters below
+//    -0.05 |oc| / |d|, far further from zero than the rounding of the roots (below 0.003 |oc| / |d|),
+//    so both roots come out negative and :125-131 reject them.
+#include "rt_tree.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rt {
+
+namespace {
+
+struct Item {
+    double c[3];
+    double r;       // radius the kernel's arithmetic sees: sqrt of the float product r*r, nudged up
+    uint32_t index;
+};
+
+struct Builder {
+    std::vector<Item> items;
+    SphereTree* out;
+    bool overflow = false;
+
+    uint32_t emit(const float g[4], uint32_t word)
+    {
+        const uint32_t at = out->node_count();
+        out->geom.insert(out->geom.end(), g, g + 4);
+        out->word.push_back(word);
+        return at;
+    }
+
+    void emit_leaf(const Item& it, const rt_gpu_sphere* spheres)
+    {
+        const float* cr = spheres[it.index].center_radius;
+        const float g[4] = { cr[0], cr[1], cr[2], cr[3] * cr[3] }; // the kernel's staging computes the same product
+        const uint32_t at = out->node_count();
+        emit(g, kTreeLeafFlag | (it.index << kTreeIndexShift) | ((at + 1u) * 16u));
+    }
+
+    // Ball around the midpoint of the bounding box of items[lo, hi); centre rounded to float first.
+    void bounding_ball(uint32_t lo, uint32_t hi, float g[4]) const
+    {
+        double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+        for (uint32_t i = lo; i < hi; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = std::min(mn[k], items[i].c[k] - items[i].r);
+                mx[k] = std::max(mx[k], items[i].c[k] + items[i].r);
+            }
+        }
+        double centre[3];
+        for (int k = 0; k < 3; ++k) {
+            g[k] = static_cast<float>(0.5 * (mn[k] + mx[k]));
+            centre[k] = g[k];
+        }
+        double radius = 0.0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double d = items[i].c[k] - centre[k];
+                d2 += d * d;
+            }
+            radius = std::max(radius, std::sqrt(d2) + items[i].r);
+        }
+        radius *= 1.0 + 1e-9; // the double arithmetic above
+        g[3] = std::nextafterf(static_cast<float>(1.125 * radius * radius), INFINITY);
+    }
+
+    // Splits items[lo, hi) in two along the longest axis of the centres' bounding box, at the
+    // spatial midpoint, or at the median when the midpoint leaves one side empty.
+    uint32_t split(uint32_t lo, uint32_t hi)
+    {
+        double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+        for (uint32_t i = lo; i < hi; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = std::min(mn[k], items[i].c[k]);
+                mx[k] = std::max(mx[k], items[i].c[k]);
+            }
+        }
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) {
+            if (mx[k] - mn[k] > mx[axis] - mn[axis]) {
+                axis = k;
+            }
+        }
+        const double mid = 0.5 * (mn[axis] + mx[axis]);
+        auto first = items.begin() + lo, last = items.begin() + hi;
+        auto cut = std::partition(first, last, [&](const Item& it) { return it.c[axis] < mid; });
+        uint32_t at = static_cast<uint32_t>(cut - items.begin());
+        if (at == lo || at == hi) {
+            at = lo + (hi - lo) / 2;
+            std::nth_element(first, items.begin() + at, last, [&](const Item& a, const Item& b) {
+                return a.c[axis] != b.c[axis] ? a.c[axis] < b.c[axis] : a.index < b.index;
+            });
+        }
+        return at;
+    }
+
+    void emit_part(uint32_t lo, uint32_t hi, const rt_gpu_sphere* spheres)
+    {
+        if (hi - lo == 1) {
+            emit_leaf(items[lo], spheres);
+            return;
+        }
+        float g[4];
+        bounding_ball(lo, hi, g);
+        const uint32_t at = emit(g, 0u);
+        emit_children(lo, hi, spheres);
+        out->word[at] = out->node_count() * 16u;
+    }
+
+    // Children of a node (or the top level): up to four parts, each a leaf or a node of its own;
+    // four or fewer spheres become leaves directly.
+    void emit_children(uint32_t lo, uint32_t hi, const rt_gpu_sphere* spheres)
+    {
+        if (out->node_count() + (hi - lo) > kTreeMaxNodes) {
+            overflow = true;
+            return;
+        }
+        if (hi - lo <= 4) {
+            for (uint32_t i = lo; i < hi; ++i) {
+                emit_leaf(items[i], spheres);
+            }
+            return;
+        }
+        const uint32_t m = split(lo, hi);
+        uint32_t cuts[5] = { lo, m, m, hi, hi };
+        int parts = 2;
+        if (hi - lo > 8) {
+            cuts[1] = split(lo, m);
+            cuts[2] = m;
+            cuts[3] = split(m, hi);
+            cuts[4] = hi;
+            parts = 4;
+        } else {
+            cuts[2] = hi;
+        }
+        for (int p = 0; p < parts; ++p) {
+            if (cuts[p + 1] > cuts[p]) {
+                emit_part(cuts[p], cuts[p + 1], spheres);
+            }
+        }
+    }
+};
+
+} // namespace
+
+bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree& out)
+{
+    out.geom.clear();
+    out.word.clear();
+    if (spheres == nullptr || count < kTreeMinSpheres || count > (kTreeLeafFlag >> kTreeIndexShift) - 1u) {
+        return false;
+    }
+    Builder b;
+    b.out = &out;
+    b.items.resize(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        const float* cr = spheres[i].center_radius;
+        const float r2 = cr[3] * cr[3];
+        for (int k = 0; k < 3; ++k) {
+            if (!(std::fabs(cr[k]) <= 0x1p20f)) {
+                return false; // also rejects NaN
+            }
+            b.items[i].c[k] = cr[k];
+        }
+        if (!(r2 >= 0x1p-40f && r2 <= 0x1p40f)) {
+            return false;
+        }
+        b.items[i].r = std::sqrt(static_cast<double>(r2)) * (1.0 + 1e-9);
+        b.items[i].index = i;
+    }
+    b.emit_children(0, count, spheres);
+    if (b.overflow || out.node_count() > kTreeMaxNodes) {
+        out.geom.clear();
+        out.word.clear();
+        return false;
+    }
+    return true;
+}
+
+} // namespace rt

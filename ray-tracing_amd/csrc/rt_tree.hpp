@@ -1,0 +1,52 @@
+// Bounding-sphere hierarchy over a sphere list, for scenes where testing every sphere against
+// every ray segment (the loop of shaders/raytrace.comp.glsl:247-259) dominates the run time.
+//
+// The hierarchy only decides WHICH spheres a ray is tested against; every sphere that is tested
+// goes through exactly the arithmetic of hitSphere (:109-133), and the closest-hit rule of
+// :254-258 (smallest accepted root, the later sphere winning an exact tie) does not depend on the
+// order of the tests.  The result is therefore identical to the loop over all spheres as long as
+// no sphere is skipped that the loop would have accepted; the inflation applied to the bounding
+// spheres below is what guarantees that, including for discriminants that only rounding makes
+// non-negative.
+//
+// Layout: one array of nodes in depth-first order.  A node is a float4 (centre, w) plus one
+// 32-bit word:
+//   leaf      w = radius^2 (the float product the brute-force loop uses)
+//             word = 1<<31 | sphere index << 17 | byte offset of the next node
+//   internal  w = 1.125 * R^2 rounded up, R = radius of a ball around `centre` that contains all
+//             spheres below the node;  word = byte offset (index * 16) of the node that follows
+//             the whole subtree
+// A ray visits node i; if the node's test fails it continues at the offset in the word, otherwise
+// at i + 1 (the first child, or simply the next node after a leaf).
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+
+namespace rt {
+
+// Scenes smaller than this are traced by the plain loop (measured crossover on MI355X: the
+// hierarchy wins from about 64 spheres on).
+constexpr uint32_t kTreeMinSpheres = 64;
+constexpr uint32_t kTreeLeafFlag = 0x80000000u;
+constexpr uint32_t kTreeOffsetMask = 0x0001FFFFu;
+constexpr uint32_t kTreeIndexShift = 17;
+// Most nodes a tree may have: offsets are 17 bits of bytes / 16.
+constexpr uint32_t kTreeMaxNodes = 8191;
+
+struct SphereTree {
+    std::vector<float> geom;     // 4 floats per node
+    std::vector<uint32_t> word;  // 1 per node
+    uint32_t node_count() const { return static_cast<uint32_t>(word.size()); }
+    bool empty() const { return word.empty(); }
+};
+
+// Builds the hierarchy.  Returns false (and leaves `out` empty) when the scene does not qualify:
+// fewer than kTreeMinSpheres spheres, or any centre/radius outside the ranges the error bounds
+// were derived for (non-finite values, |centre| > 2^20, radius^2 outside [2^-40, 2^40]).
+bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree& out);
+
+} // namespace rt

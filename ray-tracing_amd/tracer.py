@@ -59,6 +59,8 @@ ABI = {
     "rt_set_max_depth": (ctypes.c_int, [_H, _U32]),
     "rt_set_spheres": (ctypes.c_int, [_H, ctypes.POINTER(GPUSphere), _U32]),
     "rt_get_spheres": (ctypes.c_int, [_H, ctypes.POINTER(GPUSphere), _U32, ctypes.POINTER(_U32)]),
+    "rt_set_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_int]),
+    "rt_get_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.POINTER(_U32)]),
     "rt_get_params": (ctypes.c_int, [_H, _U32, ctypes.POINTER(GPUParams)]),
     "rt_reset_accumulation": (ctypes.c_int, [_H]),
     "rt_render": (ctypes.c_int, [_H, _U32, _STREAM]),
@@ -196,6 +198,22 @@ class RayTracer:
         buf = (GPUSphere * n.value)()
         self._check(self._lib.rt_get_spheres(self._h, buf, n.value, ctypes.byref(n)))
         return np.frombuffer(bytes(buf), dtype=np.float32).reshape(-1, 12).copy()
+
+    def set_scene_hierarchy(self, enable):
+        """Scenes of 64 spheres or more are traced through a bounding-sphere hierarchy (same images);
+        enable=False tests every sphere against every ray like the shader's loop (raytrace.comp.glsl:247-259)."""
+        self._check(self._lib.rt_set_scene_hierarchy(self._h, 1 if enable else 0))
+
+    def get_scene_hierarchy(self):
+        """(geom (n, 4) float32, word (n,) uint32) of the current scene's hierarchy; n = 0 if it has none."""
+        n = _U32()
+        self._check(self._lib.rt_get_scene_hierarchy(self._h, None, None, 0, ctypes.byref(n)))
+        geom = np.zeros((n.value, 4), dtype=np.float32)
+        word = np.zeros((n.value,), dtype=np.uint32)
+        if n.value:
+            self._check(self._lib.rt_get_scene_hierarchy(self._h, geom.ctypes.data, word.ctypes.data, n.value,
+                                                         ctypes.byref(n)))
+        return geom, word
 
     def get_params(self, frame_index=0):
         p = GPUParams()

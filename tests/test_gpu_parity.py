@@ -298,12 +298,16 @@ def test_frame_stride_shards(pkg, oracle):
     odd.destroy()
 
 
-@pytest.mark.parametrize("count", [2, 64, 1024, 1500, 4096])
-def test_custom_scenes(pkg, oracle, count):
-    # 1500 and 4096 spheres exercise the geometry-only LDS layout (materials fetched from global memory)
+@pytest.mark.parametrize("count,hierarchy", [(2, True), (63, True), (64, True), (64, False), (1024, True), (1024, False),
+                                             (1500, True), (1500, False), (4096, True), (4096, False)])
+def test_custom_scenes(pkg, oracle, count, hierarchy):
+    # with the hierarchy off, 1500 and 4096 spheres exercise the geometry-only LDS layout of the loop
+    # over all spheres (materials fetched from global memory); with it on, scenes of 64 spheres or
+    # more are walked through the bounding-sphere hierarchy
     scene = pkg.synthetic_scene(count)
     w, h = (48, 32) if count > 1024 else (80, 48)
     t = make_tracer(pkg, w, h, 2, 6, 0.05, scene=scene)
+    t.set_scene_hierarchy(hierarchy)
     t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
     t.enable_rng_capture(True)
     t.render_frames(0, 2)

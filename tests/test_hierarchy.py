@@ -1,0 +1,291 @@
+"""The bounding-sphere hierarchy for large scenes: structure, the guarantee that it never skips a
+sphere the plain loop (shaders/raytrace.comp.glsl:247-259) would have accepted, and GPU parity with
+the loop over all spheres."""
+import numpy as np
+import pytest
+
+F = np.float32
+LEAF = 0x80000000
+KEEP = F(1.0) - F(2.0 ** -13)
+
+
+def _host(pkg, scene):
+    t = pkg.RayTracer().create(64, 64, device_id=-1)
+    t.set_spheres(scene)
+    return t
+
+
+def _cluster_scene(pkg, count=300, seed=5):
+    """Tight clumps, nested and coincident spheres, and a wide range of radii."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((count, 12), dtype=np.float32)
+    out[:, 4:7] = rng.random((count, 3), dtype=np.float32)
+    out[:, 8] = rng.integers(0, 3, count).astype(np.float32)
+    out[:, 9] = rng.random(count, dtype=np.float32) * 0.3
+    out[:, 10] = 1.5
+    centres = rng.normal(size=(12, 3)).astype(np.float32) * 6.0
+    for i in range(count):
+        c = centres[i % 12]
+        out[i, 0:3] = c + rng.normal(size=3).astype(np.float32) * np.float32(0.8)
+        out[i, 3] = np.float32(10.0 ** rng.uniform(-2.0, 0.3))
+    out[0] = [0.0, -500.0, 0.0, 495.0, 0.5, 0.5, 0.5, 0.0, 0.0, 0.0, 1.0, 1.0]
+    out[10:20] = out[20:30]                      # coincident spheres: exact ties, the later index must win
+    out[10:20, 4:7] = 0.9
+    out[40:50, 0:3] = out[50:60, 0:3]            # concentric, different radii
+    return out
+
+
+def _check_structure(scene, geom, word):
+    n = len(word)
+    leaf = (word & LEAF) != 0
+    assert leaf.sum() == len(scene)
+    index = (word[leaf] & 0x7FFFFFFF) >> 17
+    assert sorted(index.tolist()) == list(range(len(scene)))
+    # a leaf holds the sphere's centre and the float product r * r, and continues at the next node
+    s = scene[index]
+    assert np.array_equal(geom[leaf, :3], s[:, :3])
+    assert np.array_equal(geom[leaf, 3], s[:, 3] * s[:, 3])
+    at = np.nonzero(leaf)[0]
+    assert np.array_equal((word[leaf] & 0x1FFFF), ((at + 1) * 16).astype(np.uint32))
+    # an inner node's ball (R^2 = w / 1.125) contains every sphere of its subtree, which ends where
+    # its offset points
+    for i in np.nonzero(~leaf)[0]:
+        assert word[i] % 16 == 0
+        end = int(word[i]) // 16
+        assert i + 1 < end <= n
+        sub = np.arange(i + 1, end)
+        sl = sub[leaf[sub]]
+        assert len(sl) >= 2
+        centre = geom[i, :3].astype(np.float64)
+        radius = np.sqrt(float(geom[i, 3]) / 1.125)
+        c = geom[sl, :3].astype(np.float64)
+        r = np.sqrt(geom[sl, 3].astype(np.float64))
+        assert np.all(np.sqrt(((c - centre) ** 2).sum(1)) + r <= radius * (1.0 + 1e-6))
+        # subtrees nest: a child's subtree ends inside its parent's
+        inner = sub[~leaf[sub]]
+        assert np.all(word[inner] // 16 <= end)
+
+
+@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "random", "clusters"])
+def test_structure(pkg, name):
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "synthetic100": lambda: pkg.synthetic_scene(100),
+             "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
+    t = _host(pkg, scene)
+    geom, word = t.get_scene_hierarchy()
+    assert 0 < len(word) <= 8191
+    _check_structure(scene, geom, word)
+    # the same scene gives the same hierarchy
+    t2 = _host(pkg, scene)
+    geom2, word2 = t2.get_scene_hierarchy()
+    assert np.array_equal(geom, geom2) and np.array_equal(word, word2)
+    t.destroy()
+    t2.destroy()
+
+
+def test_scenes_without_hierarchy(pkg):
+    t = pkg.RayTracer().create(64, 64, device_id=-1)
+    assert len(t.get_scene_hierarchy()[1]) == 0           # the default five spheres
+    t.set_spheres(pkg.synthetic_scene(63))
+    assert len(t.get_scene_hierarchy()[1]) == 0           # below the threshold
+    t.set_spheres(pkg.synthetic_scene(64))
+    assert len(t.get_scene_hierarchy()[1]) > 0
+    for field, value in ((0, np.nan), (1, np.inf), (2, 3.0e6), (3, 0.0), (3, 1.0e-25), (3, 2.0e20), (3, np.nan)):
+        scene = pkg.synthetic_scene(200)
+        scene[77, field] = value
+        t.set_spheres(scene)
+        assert len(t.get_scene_hierarchy()[1]) == 0, (field, value)
+    t.set_spheres(pkg.synthetic_scene(200))
+    assert len(t.get_scene_hierarchy()[1]) > 0
+    t.destroy()
+
+
+def _dot(a, b):
+    # left-to-right float32 sum of products, like the kernel's dot()
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def _quadratic(centre, w, o, d, a, scale):
+    oc = o - centre
+    hb = _dot(oc, d)
+    c = _dot(oc, oc) * scale - w
+    disc = hb * hb - a * c
+    return hb, c, disc
+
+
+def _passes(hb, c, disc):
+    """The two tests ahead of the square root: negative discriminant; centre behind the origin of a
+    ray that starts outside (neither half_b nor c has its sign bit set)."""
+    behind = ((hb.view(np.uint32) | c.view(np.uint32)) & np.uint32(0x80000000)) == 0
+    return ~((disc < F(0.0)) | behind)
+
+
+def _accepted(hb, disc, a, tmin=F(0.001), tmax=F(1e20)):
+    """hitSphere's root selection (raytrace.comp.glsl:121-131) in float32: whether the sphere yields a
+    root inside [tmin, tmax].  1e20 is the loop's initial `closest`, so this is every sphere the loop
+    over all spheres could ever accept."""
+    with np.errstate(invalid="ignore"):
+        sq = np.sqrt(np.where(disc < F(0.0), F(0.0), disc))
+        near = (-hb - sq) / a
+        far = (-hb + sq) / a
+    near_out = (near < tmin) | (near > tmax)
+    far_out = (far < tmin) | (far > tmax)
+    return ~(disc < F(0.0)) & ~(near_out & far_out)
+
+
+def _visited_leaves(geom, word, o, d):
+    """Walks the hierarchy for every ray at once, in float32 like the kernel; returns a (rays, nodes)
+    mask of the leaves each ray reached."""
+    n = len(word)
+    rays = o.shape[0]
+    a = _dot(d, d)
+    at = np.zeros(rays, dtype=np.int64)
+    visited = np.zeros((rays, n), dtype=bool)
+    leaf = (word & LEAF) != 0
+    skip = (word & 0x1FFFF).astype(np.int64) // 16
+    lanes = np.arange(rays)
+    for _ in range(n + 1):
+        live = at < n
+        if not live.any():
+            break
+        idx = np.where(live, at, 0)
+        scale = np.where(leaf[idx], F(1.0), KEEP).astype(np.float32)
+        hb, c, disc = _quadratic(geom[idx, :3], geom[idx, 3], o, d, a, scale)
+        ok = _passes(hb, c, disc)
+        visited[lanes[live & leaf[idx]], idx[live & leaf[idx]]] = True
+        at = np.where(live, np.where(ok, at + 1, skip[idx]), at)
+    else:
+        raise AssertionError("a traversal did not terminate")
+    return visited
+
+
+def _rays(scene, count, seed):
+    """Camera-like, surface-born, far-away and grazing rays; directions of assorted lengths."""
+    rng = np.random.default_rng(seed)
+    o = np.zeros((count, 3), dtype=np.float32)
+    d = np.zeros((count, 3), dtype=np.float32)
+    for i in range(count):
+        kind = i % 5
+        s = scene[rng.integers(0, len(scene))]
+        target = s[:3] + rng.normal(size=3) * s[3]
+        if kind == 0:      # from a camera position
+            origin = np.array([3.0, 1.5, 6.0]) + rng.normal(size=3) * 0.01
+        elif kind == 1:    # from the surface of another sphere
+            q = scene[rng.integers(0, len(scene))]
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            origin = q[:3] + n * q[3] * 1.001
+        elif kind == 2:    # from far away
+            n = rng.normal(size=3)
+            origin = n / np.linalg.norm(n) * 10.0 ** rng.uniform(1.5, 4.0)
+        elif kind == 3:    # grazing: aimed at the silhouette of a sphere
+            origin = np.array([3.0, 1.5, 6.0]) + rng.normal(size=3) * 3.0
+            to = s[:3] - origin
+            side = np.cross(to, rng.normal(size=3))
+            side /= np.linalg.norm(side)
+            target = s[:3] + side * s[3] * (1.0 + rng.normal() * 1e-6)
+        else:              # from inside a cluster, any direction
+            origin = s[:3] + rng.normal(size=3) * 2.0
+            target = origin + rng.normal(size=3)
+        direction = target - origin
+        direction *= 10.0 ** rng.uniform(-2.0, 2.0) / np.linalg.norm(direction)
+        o[i] = origin
+        d[i] = direction
+    return o, d
+
+
+@pytest.mark.parametrize("name", ["synthetic4096", "random", "clusters"])
+def test_no_accepted_sphere_is_skipped(pkg, name):
+    """For every ray, each sphere whose float32 evaluation of hitSphere yields a root in [tmin, 1e20]
+    is a leaf the walk reaches (and is then evaluated exactly as in the loop over all spheres)."""
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "random": pkg.random_scene,
+             "clusters": lambda: _cluster_scene(pkg)}[name]()
+    t = _host(pkg, scene)
+    geom, word = t.get_scene_hierarchy()
+    t.destroy()
+    leaf_nodes = np.nonzero((word & LEAF) != 0)[0]
+    sphere_of = ((word[leaf_nodes] & 0x7FFFFFFF) >> 17).astype(np.int64)
+    node_of_sphere = np.zeros(len(scene), dtype=np.int64)
+    node_of_sphere[sphere_of] = leaf_nodes
+    rays = 1500 if name == "synthetic4096" else 3000
+    o, d = _rays(scene, rays, seed=11)
+    a = _dot(d, d)
+    assert np.all((a >= F(2.0 ** -20)) & (a <= F(2.0 ** 20)))
+    visited = _visited_leaves(geom, word, o, d)
+    centre = scene[:, :3]
+    r2 = scene[:, 3] * scene[:, 3]
+    missed = 0
+    reached = 0
+    candidates = 0
+    for lo in range(0, rays, 250):
+        sl = slice(lo, lo + 250)
+        hb, c, disc = _quadratic(centre[None, :, :], r2[None, :], o[sl, None, :], d[sl, None, :], a[sl, None], F(1.0))
+        ok = _accepted(hb, disc, a[sl, None])
+        seen = visited[sl][:, node_of_sphere]
+        missed += int((ok & ~seen).sum())
+        candidates += int(ok.sum())
+        reached += int(seen.sum())
+    assert missed == 0
+    assert candidates > rays // 2                  # the rays do meet spheres
+    assert reached < 0.2 * rays * len(scene)       # and the walk does prune
+
+
+# ---------------------------------------------------------------------------------------- GPU
+def _render(pkg, scene, hierarchy, w=160, h=96, spp=4, depth=12, frames=3, camera=None, focus=6.0, aperture=0.05):
+    t = pkg.RayTracer().create(w, h, device_id=0)
+    t.set_samples_per_pixel(spp)
+    t.set_max_depth(depth)
+    t.set_aperture(aperture)
+    t.set_spheres(scene)
+    pos, look = camera or ([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0])
+    t.set_camera(pos, look, focus)
+    t.set_scene_hierarchy(hierarchy)
+    t.enable_rng_capture(True)
+    t.render_frames(0, frames)
+    out = (t.read_accum(), t.read_rng_state(), t.read_output())
+    t.destroy()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["synthetic4096", "synthetic700", "random", "clusters"])
+def test_hierarchy_matches_loop_on_gpu(pkg, name):
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "synthetic700": lambda: pkg.synthetic_scene(700),
+             "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
+    camera = ([13.0, 2.0, 3.0], [-13.0, -1.0, -3.0]) if name == "random" else None
+    if name == "clusters":
+        camera = ([0.0, 4.0, 30.0], [0.0, -0.1, -1.0])
+    a = _render(pkg, scene, True, camera=camera)
+    b = _render(pkg, scene, False, camera=camera)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    assert np.any(a[0][..., :3] > 0.0)
+
+
+@pytest.mark.gpu
+def test_hierarchy_ties_and_oracle(pkg, oracle):
+    """Coincident spheres give exactly equal roots; the later index must win as in the shader's loop."""
+    from test_gpu_parity import oracle_frames, same
+    scene = _cluster_scene(pkg, count=120)
+    t = pkg.RayTracer().create(96, 64, device_id=0)
+    t.set_samples_per_pixel(2)
+    t.set_max_depth(8)
+    t.set_spheres(scene)
+    t.set_camera([0.0, 4.0, 30.0], [0.0, -0.1, -1.0], 30.0)
+    t.enable_rng_capture(True)
+    assert len(t.get_scene_hierarchy()[1]) > 0
+    t.render_frames(0, 2)
+    ref = oracle_frames(oracle, t, scene, [0, 1], want_rng=True)
+    assert same(t.read_rng_state(), ref["rng"])
+    assert same(t.read_accum(), ref["accum"])
+    t.destroy()
+
+
+@pytest.mark.gpu
+def test_rays_outside_the_proven_range_use_the_loop(pkg):
+    """A focus distance of 4000 makes the camera rays' dot(d,d) exceed 2^20: those rays must take the
+    plain loop inside the hierarchy kernel, and the image must not change."""
+    scene = pkg.synthetic_scene(500)
+    a = _render(pkg, scene, True, focus=4000.0, aperture=0.0)
+    b = _render(pkg, scene, False, focus=4000.0, aperture=0.0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))

@@ -54,7 +54,7 @@ constexpr float kTMin = 0.001f;
 // number of active lanes.  The shipped library instantiates the kernel with NoStats only.
 enum Section {
     ST_ITER, ST_ITEM, ST_GEN, ST_DISK_IT, ST_NORM2, ST_ROOT, ST_FAR_ROOT, ST_HIT, ST_RIS, ST_RIS_IT,
-    ST_SKY, ST_LAMBERT, ST_CHECKER, ST_METAL, ST_DIEL, ST_SCHLICK, ST_COUNT
+    ST_SKY, ST_LAMBERT, ST_CHECKER, ST_METAL, ST_DIEL, ST_SCHLICK, ST_NODE, ST_COUNT
 };
 
 enum Phase { PH_NORM2, PH_INTERSECT, PH_HIT, PH_ITEM, PH_SAMPLER, PH_NORM1, PH_SHADE, PH_TAIL, PH_COUNT };
@@ -168,6 +168,86 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Closest hit of one ray segment over the whole scene, raytrace.comp.glsl:244-259: `closest` and
+// `best` come back as the loop of :247-259 leaves them (1e20 and -1 without a hit).
+template <int MODE, class Stats>
+__device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* geom, const uint32_t* node_word, uint32_t sphere_count,
+                                            f3 ro, f3 rd, RayDenominator& rden, float& closest, int& best, Stats& st)
+{
+    constexpr bool MAT_IN_LDS = MODE == kFullLds;
+    closest = 1e20f;
+    best = -1;
+    if (MODE == kTree) {
+        rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
+        // the skip tests of the hierarchy are proven for rays in the bounded range only
+        if (rden.bounded) {
+            const uint32_t end = A.tree_nodes * 16u;
+            uint32_t at = 0; // byte offset of this lane's node
+            while (at < end) {
+                st.section(ST_NODE);
+                const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + at);
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (at >> 2));
+                // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
+                const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
+                const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, rden.a, k);
+                uint32_t next = at + 16u;
+                if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c)) {
+                    next = w & kTreeOffsetMask;
+                } else if ((int32_t)w < 0) {
+                    sphere_closest_any_order(q, rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), closest, best, st);
+                }
+                at = next;
+            }
+        } else {
+            RT_COLD_PATH();
+            for (uint32_t i = 0; i < sphere_count; ++i) {
+                const float4 cr = *reinterpret_cast<const float4*>(A.spheres + i);
+                const float4 g = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
+                sphere_closest(sphere_quadratic(g, ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
+            }
+        }
+        return;
+    }
+    rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
+    uint32_t i = 0;
+    if (!MAT_IN_LDS) {
+        // Large scenes: four records per trip, fetched together so that one LDS wait covers
+        // them and the four discriminants overlap; the roots are still resolved in index
+        // order (an equal-t later sphere replaces an earlier one, :125 with tMax = closest).
+        for (; i + 4u <= sphere_count; i += 4u) {
+            const float4 g0 = geom[i], g1 = geom[i + 1u], g2 = geom[i + 2u], g3 = geom[i + 3u];
+            const SphereQuadratic q0 = sphere_quadratic(g0, ro, rd, rden.a);
+            const SphereQuadratic q1 = sphere_quadratic(g1, ro, rd, rden.a);
+            const SphereQuadratic q2 = sphere_quadratic(g2, ro, rd, rden.a);
+            const SphereQuadratic q3 = sphere_quadratic(g3, ro, rd, rden.a);
+            // one branch per four spheres: almost always all four discriminants are negative
+            if (!(q0.discriminant < 0.0f) || !(q1.discriminant < 0.0f) || !(q2.discriminant < 0.0f) ||
+                !(q3.discriminant < 0.0f)) {
+                float root;
+                if (sphere_root_from(q0, rden, kTMin, closest, root, st)) {
+                    closest = root;
+                    best = (int)i;
+                }
+                if (sphere_root_from(q1, rden, kTMin, closest, root, st)) {
+                    closest = root;
+                    best = (int)i + 1;
+                }
+                if (sphere_root_from(q2, rden, kTMin, closest, root, st)) {
+                    closest = root;
+                    best = (int)i + 2;
+                }
+                if (sphere_root_from(q3, rden, kTMin, closest, root, st)) {
+                    closest = root;
+                    best = (int)i + 3;
+                }
+            }
+        }
+    }
+    for (; i < sphere_count; ++i) {
+        sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
+    }
+}
+
 // BLOCK = threads per workgroup: 256 for scenes whose whole records fit in LDS, 512 for the
 // geometry-only layout (64 KiB of LDS per workgroup: two workgroups, 16 waves, per CU); the
 // hierarchy uses 256, 512 or 1024 depending on its size.
@@ -277,75 +357,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         rden.rcp_a = 1.0f;
         rden.a_ok = true;
         rden.bounded = false;
-        if (MODE == kTree) {
-            if (live) {
-                rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
-                // the skip tests of the hierarchy are proven for rays in the bounded range only
-                if (rden.bounded) {
-                    const uint32_t end = A.tree_nodes * 16u;
-                    uint32_t at = 0; // byte offset of this lane's node
-                    while (at < end) {
-                        const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + at);
-                        const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (at >> 2));
-                        // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
-                        const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
-                        const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, rden.a, k);
-                        uint32_t next = at + 16u;
-                        if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c)) {
-                            next = w & kTreeOffsetMask;
-                        } else if ((int32_t)w < 0) {
-                            sphere_closest_any_order(q, rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), closest, best, st);
-                        }
-                        at = next;
-                    }
-                } else {
-                    RT_COLD_PATH();
-                    for (uint32_t i = 0; i < sphere_count; ++i) {
-                        const float4 cr = *reinterpret_cast<const float4*>(A.spheres + i);
-                        const float4 g = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
-                        sphere_closest(sphere_quadratic(g, ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
-                    }
-                }
-            }
-        } else if (live) {
-            rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
-            uint32_t i = 0;
-            if (!MAT_IN_LDS) {
-                // Large scenes: four records per trip, fetched together so that one LDS wait covers
-                // them and the four discriminants overlap; the roots are still resolved in index
-                // order (an equal-t later sphere replaces an earlier one, :125 with tMax = closest).
-                for (; i + 4u <= sphere_count; i += 4u) {
-                    const float4 g0 = geom[i], g1 = geom[i + 1u], g2 = geom[i + 2u], g3 = geom[i + 3u];
-                    const SphereQuadratic q0 = sphere_quadratic(g0, ro, rd, rden.a);
-                    const SphereQuadratic q1 = sphere_quadratic(g1, ro, rd, rden.a);
-                    const SphereQuadratic q2 = sphere_quadratic(g2, ro, rd, rden.a);
-                    const SphereQuadratic q3 = sphere_quadratic(g3, ro, rd, rden.a);
-                    // one branch per four spheres: almost always all four discriminants are negative
-                    if (!(q0.discriminant < 0.0f) || !(q1.discriminant < 0.0f) || !(q2.discriminant < 0.0f) ||
-                        !(q3.discriminant < 0.0f)) {
-                        float root;
-                        if (sphere_root_from(q0, rden, kTMin, closest, root, st)) {
-                            closest = root;
-                            best = (int)i;
-                        }
-                        if (sphere_root_from(q1, rden, kTMin, closest, root, st)) {
-                            closest = root;
-                            best = (int)i + 1;
-                        }
-                        if (sphere_root_from(q2, rden, kTMin, closest, root, st)) {
-                            closest = root;
-                            best = (int)i + 2;
-                        }
-                        if (sphere_root_from(q3, rden, kTMin, closest, root, st)) {
-                            closest = root;
-                            best = (int)i + 3;
-                        }
-                    }
-                }
-            }
-            for (; i < sphere_count; ++i) {
-                sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
-            }
+        if (live) {
+            closest_hit<MODE>(A, geom, node_word, sphere_count, ro, rd, rden, closest, best, st);
         }
         st.phase_end(PH_INTERSECT);
         const bool hit = best >= 0; // only live lanes can hit

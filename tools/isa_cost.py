@@ -1,30 +1,35 @@
 #!/usr/bin/env python3
 """Issue-slot cost model of the trace kernel's ISA: per basic block, the number of VALU instructions
 and their cost in units of one full-rate VALU instruction (rates measured by tools/ubench/valu_rates.hip
-on MI355X: add/mul/fma/logic/mov = 1, packed f32 = 1.75, compare/cvt/min/max/int-mul/div-helpers = 1.65,
-rcp/sqrt/rsq = 3.3).  Usage: python tools/isa_cost.py /tmp/rt_kernels.s [kernel-name-substring]"""
+on MI355X: f32 add/sub/mul/fma, u32 add/sub, and/or/xor, right shifts and mov with VGPR, literal or
+inline operands = 1; the same with an SGPR operand, left shifts, compares, selects, conversions,
+min/max, integer multiplies, three-operand integer ops, DPP and the division helpers = 1.8;
+packed f32 = 2; rcp/sqrt/rsq = 3.5).  Usage: python tools/isa_cost.py /tmp/rt_kernels.s [kernel-name-substring]"""
 import re
 import sys
 
 FULL = ('v_add_f32', 'v_sub_f32', 'v_subrev_f32', 'v_mul_f32', 'v_fma_f32', 'v_fmac_f32', 'v_mac_f32', 'v_and_b32',
-        'v_or_b32', 'v_xor_b32', 'v_lshlrev_b32', 'v_lshrrev_b32', 'v_add_u32', 'v_sub_u32', 'v_subrev_u32',
-        'v_mov_b32', 'v_add_co_u32', 'v_addc_co_u32', 'v_not_b32', 'v_mov_b64', 'v_ashrrev_i32', 'v_lshlrev_b64')
+        'v_or_b32', 'v_xor_b32', 'v_lshrrev_b32', 'v_add_u32', 'v_sub_u32', 'v_subrev_u32',
+        'v_mov_b32', 'v_not_b32', 'v_ashrrev_i32')
 TRANS = ('v_rcp', 'v_sqrt', 'v_rsq', 'v_exp', 'v_log')
 
 
-def cost(op):
+SGPR_OPERAND = re.compile(r'[ ,]s\d+\b|[ ,]s\[\d+:\d+\]|\bvcc\b')
+
+
+def cost(op, operands=''):
     if op.startswith(TRANS):
-        return 3.3
+        return 3.5
     if op.startswith('v_pk_'):
-        return 1.75
-    if op.startswith(FULL):
+        return 2.0
+    if op.startswith(FULL) and not SGPR_OPERAND.search(' ' + operands):
         return 1.0
-    return 1.65
+    return 1.8
 
 
 def main():
     path = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else 'rt_trace_kernelILb1ENS0_7NoStats'
+    want = sys.argv[2] if len(sys.argv) > 2 else 'rt_trace_kernelILi1ENS0_7NoStats'
     text = open(path).read().split('\n')
     inside = False
     blocks = []
@@ -49,7 +54,7 @@ def main():
         op = tok[0]
         if op.startswith('v_'):
             cur['n'] += 1
-            cur['units'] += cost(op)
+            cur['units'] += cost(op, ' '.join(tok[1:]))
             short = op.replace('_e32', '').replace('_e64', '')
             cur['ops'][short] = cur['ops'].get(short, 0) + 1
     total = 0.0

@@ -15,6 +15,8 @@ CONFIGS = {
     "c2": (1920, 1080, 16, 8, 0.0, 64, "default"),
     "c3": (3840, 2160, 64, 16, 0.05, 64, "default"),
     "c4": (7680, 4320, 256, 8, 0.05, 1, "default"),
+    "c2f": (1920, 1080, 16, 8, 0.0, 1, "default"),      # one frame per launch, as App::run drives it
+    "c2q": (1920, 1080, 4, 12, 0.05, 1, "default"),     # the application's defaults: 4 spp, depth 12
     "c5": (1920, 1080, 16, 50, 0.05, 1, "synthetic4096"),
     "c5s": (480, 270, 16, 50, 0.05, 1, "synthetic4096"),
     "c5m": (960, 540, 16, 50, 0.05, 4, "synthetic4096"),

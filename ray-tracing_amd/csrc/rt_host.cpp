@@ -385,9 +385,19 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             h->partial_bytes = need;
         }
     }
-    uint32_t frames_per_unit = 16;
+    // Unit geometry (frames pooled per unit, pixel tile): defaults are chosen by launch_trace;
+    // RT_FRAMES_PER_UNIT and RT_TILE_LOG2="w h" override them for experiments.
+    uint32_t frames_per_unit = 64;
     if (const char* e = std::getenv("RT_FRAMES_PER_UNIT")) {
         frames_per_unit = static_cast<uint32_t>(std::max(1, std::atoi(e)));
+    }
+    uint32_t tile_w_log2 = 0xFFu, tile_h_log2 = 0xFFu;
+    if (const char* e = std::getenv("RT_TILE_LOG2")) {
+        unsigned w = 0, hgt = 0;
+        if (std::sscanf(e, "%u %u", &w, &hgt) == 2 && w <= 3 && hgt <= 3) {
+            tile_w_log2 = w;
+            tile_h_log2 = hgt;
+        }
     }
 
     for (uint32_t done = 0; done < n_frames; done += group) {
@@ -415,6 +425,8 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.n_frames = count;
         args.frame_stride = frame_stride;
         args.frames_per_unit = frames_per_unit;
+        args.tile_w_log2 = tile_w_log2;
+        args.tile_h_log2 = tile_h_log2;
         args.tiles_x = args.n_tiles = args.n_chunks = 0;
 
         const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);

@@ -39,6 +39,8 @@ struct TraceArgs {
     uint32_t n_frames;
     uint32_t frame_stride;
     uint32_t frames_per_unit;     // frames of one tile a wave pools together (1..64)
+    uint32_t tile_w_log2;         // pixel tile of a unit, 2^w x 2^h with w, h <= 3; anything larger = let launch_trace choose
+    uint32_t tile_h_log2;
     // filled in by launch_trace
     uint32_t tiles_x;
     uint32_t n_tiles;

@@ -7,9 +7,7 @@ for round in 1 2; do
     lib=${spec##* }
     envargs=()
     IFS=',' read -ra parts <<< "$settings"
-    for kv in "${parts[@]}"; do envargs+=("${kv//_/ }"); done
-    envargs=("${envargs[@]/RT FRAMES PER UNIT/RT_FRAMES_PER_UNIT}")
-    envargs=("${envargs[@]/RT TILE LOG2/RT_TILE_LOG2}")
+    for kv in "${parts[@]}"; do name=${kv%%=*}; value=${kv#*=}; envargs+=("$name=${value//_/ }"); done
     env "${envargs[@]}" RT_MI355X_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-60s %.2f Gs/s  kernel %.2f ms' % ('$spec', d['value']/1e9, d['roofline']['kernel_ms']))" || exit 1
   done
 done

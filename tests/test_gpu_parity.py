@@ -318,6 +318,21 @@ def test_custom_scenes(pkg, oracle, count, hierarchy):
     t.destroy()
 
 
+@pytest.mark.parametrize("w,h,frames", [(37, 23, 64), (45, 31, 20), (19, 9, 40), (8, 4, 64), (3, 2, 7)])
+def test_unit_geometries_with_ragged_tiles(pkg, oracle, w, h, frames):
+    """The pixel tile of a unit shrinks as the launch gets more frames (8x8 for one frame down to 2x4
+    for 64); image sizes that are no multiple of any of them must still cover every pixel once."""
+    scene = pkg.default_scene()
+    t = make_tracer(pkg, w, h, 2, 6, 0.05)
+    t.enable_rng_capture(True)
+    t.render_frames(0, frames)
+    ref = oracle_frames(oracle, t, scene, range(frames), want_rng=True)
+    assert same(t.read_rng_state(), ref["rng"])
+    assert same(t.read_accum(), ref["accum"])
+    assert same(t.read_output(), ref["output"])
+    t.destroy()
+
+
 def test_full_1080p_frame_bit_exact(pkg, oracle):
     # the benchmark configuration (1920x1080, 16 spp, depth 8, DoF off), one frame
     t = make_tracer(pkg, 1920, 1080, 16, 8, 0.0)

@@ -328,6 +328,13 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const float inv_w = A.params.inv_resolution[0];
     const float inv_h = A.params.inv_resolution[1];
     const float res_y_minus_1 = A.params.resolution[1] - 1.0f; // float(params.resolution.y - 1u ...), :320
+    // With a lens radius of zero the lens offset of :324-325 is +-0 in every component.  Subtracting
+    // it from the direction and adding it to the origin then changes nothing, except the sign of a
+    // zero: origin + (+-0) can differ from origin only where an origin component is itself zero, and
+    // (x - origin) - (+-0) only where x - origin is -0, which needs a zero origin component too
+    // (an exact cancellation rounds to +0).  So for a pinhole camera whose position has no zero
+    // component both steps are skipped; the two draws of randomInUnitDisk are still consumed.
+    const bool pinhole = lens_radius == 0.0f && origin.x != 0.0f && origin.y != 0.0f && origin.z != 0.0f;
 
     // ---- per-lane state ----
     bool has_item = false;
@@ -580,11 +587,16 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
 
         // ------------------------------------------------------------------ camera ray, :322-328
         if (gen) {
-            float rdx = lens_radius * ris.x;
-            float rdy = lens_radius * ris.y;
-            f3 offset = cam_u * rdx + cam_v * rdy;
-            rd = lower_left + horizontal * u_coord + vertical * v_coord - origin - offset;
-            ro = origin + offset;
+            if (pinhole) {
+                rd = lower_left + horizontal * u_coord + vertical * v_coord - origin;
+                ro = origin;
+            } else {
+                float rdx = lens_radius * ris.x;
+                float rdy = lens_radius * ris.y;
+                f3 offset = cam_u * rdx + cam_v * rdy;
+                rd = lower_left + horizontal * u_coord + vertical * v_coord - origin - offset;
+                ro = origin + offset;
+            }
             pending_norm = true;
             throughput = mk(1.0f, 1.0f, 1.0f);
             depth = 0u;

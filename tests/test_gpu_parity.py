@@ -333,6 +333,22 @@ def test_unit_geometries_with_ragged_tiles(pkg, oracle, w, h, frames):
     t.destroy()
 
 
+@pytest.mark.parametrize("pos", [(13.0, 2.0, 3.0), (0.0, 2.0, 9.0), (-0.0, 2.0, 9.0), (5.0, 0.0, -0.0), (0.0, 0.5, 0.0)])
+def test_pinhole_camera_positions(pkg, oracle, pos):
+    """Aperture 0: the lens offset is +-0.  The kernel skips it only when no component of the camera
+    position is zero; zero (and minus zero) components must give the oracle's bits as well."""
+    scene = pkg.default_scene()
+    t = make_tracer(pkg, 96, 54, 3, 8, 0.0)
+    t.set_camera(list(pos), [0.1 - pos[0], 1.0 - pos[1], 0.2 - pos[2]], 8.0)
+    t.enable_rng_capture(True)
+    t.render_frames(0, 2)
+    ref = oracle_frames(oracle, t, scene, [0, 1], want_rng=True)
+    assert same(t.read_rng_state(), ref["rng"])
+    assert same(t.read_accum(), ref["accum"])
+    assert same(t.read_output(), ref["output"])
+    t.destroy()
+
+
 def test_full_1080p_frame_bit_exact(pkg, oracle):
     # the benchmark configuration (1920x1080, 16 spp, depth 8, DoF off), one frame
     t = make_tracer(pkg, 1920, 1080, 16, 8, 0.0)

@@ -78,6 +78,8 @@ def lib():
         L.rto_powf.argtypes = [ctypes.c_float, ctypes.c_float]
         L.rto_default_scene.argtypes = [ctypes.POINTER(Sphere)]
         L.rto_normalize3.argtypes = [f32p, f32p]
+        L.rto_builtin.restype = ctypes.c_int
+        L.rto_builtin.argtypes = [ctypes.c_char_p, f32p, f32p]
         L.rto_make_camera_params.argtypes = [f32p, f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                              ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Params)]
         L.rto_default_aim.argtypes = [f32p, f32p, f32p]
@@ -123,6 +125,19 @@ def normalize3(v):
     out = (ctypes.c_float * 3)()
     lib().rto_normalize3(_f3(v), out)
     return [out[0], out[1], out[2]]
+
+
+def builtin(op, inputs):
+    """The oracle's GLSL built-in `op` on float32 inputs -> list of float32 results (see rto_builtin)."""
+    arr = np.ascontiguousarray(inputs, dtype=np.float32)
+    buf = (ctypes.c_float * 8)(*([0.0] * 8))
+    for i, v in enumerate(arr):
+        buf[i] = v
+    out = (ctypes.c_float * 4)()
+    n = lib().rto_builtin(op.encode(), buf, out)
+    if n < 0:
+        raise ValueError("unknown built-in %r" % (op,))
+    return np.array(out[:n], dtype=np.float32)
 
 
 def default_aim(pos=(13.0, 2.0, 3.0)):

@@ -32,6 +32,14 @@ static inline float inversesqrt(float x) { return 1.0f / sqrtf(x); }
 static inline v3 normalize(v3 a) { return scale(a, inversesqrt(dot(a, a))); }
 /* reflect(I, N) = I - 2.0 * dot(N, I) * N */
 static inline v3 reflect(v3 i, v3 n) { return sub(i, scale(n, 2.0f * dot(n, i))); }
+/* GLSL mix(x, y, a) = x * (1 - a) + y * a, per component with a scalar a */
+static inline v3 mix3(v3 x, v3 y, float a)
+{
+    float oma = 1.0f - a;
+    return V(x.x * oma + y.x * a, x.y * oma + y.y * a, x.z * oma + y.z * a);
+}
+/* GLSL mod(x, y) = x - y * floor(x / y) */
+static inline float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -344,7 +352,7 @@ static int scatter_lambert(const hit_t *h, v3 *attenuation, ray_t *next, ctx_t *
     cx->c->lambert++;
     if (h->flags > 0.5f) {
         float checker_index = floorf(h->p.x) + floorf(h->p.z);
-        float checker = checker_index - 2.0f * floorf(checker_index / 2.0f);
+        float checker = glsl_mod(checker_index, 2.0f); /* :166 */
         float tone = (checker < 1.0f) ? 0.05f : 0.95f;
         albedo = scale(albedo, tone);
         cx->c->lambert_checker++;
@@ -452,9 +460,7 @@ static v3 trace_ray(const rto_params *params, const rto_sphere *spheres, ray_t r
         if (!best.hit) {
             v3 unit_dir = normalize(ray.d);
             float t = 0.5f * (unit_dir.y + 1.0f);
-            float omt = 1.0f - t;
-            /* mix(vec3(1.0), vec3(0.5,0.7,1.0), t) = x*(1-t) + y*t */
-            v3 sky = V(1.0f * omt + 0.5f * t, 1.0f * omt + 0.7f * t, 1.0f * omt + 1.0f * t);
+            v3 sky = mix3(V(1.0f, 1.0f, 1.0f), V(0.5f, 0.7f, 1.0f), t); /* :265 */
             radiance = add(radiance, mul(throughput, sky));
             cx->c->sky++;
             return radiance;
@@ -631,6 +637,26 @@ int rto_render(const rto_params *params, const rto_sphere *spheres,
     free(jobs);
     free(th);
     return 0;
+}
+
+/* Test hook: the helpers above by name, so that fixtures produced with the reference's vendored GLM
+ * can pin them.  Returns the number of floats written to out, or -1 for an unknown name. */
+int rto_builtin(const char *op, const float *in, float *out)
+{
+    v3 a = V(in[0], in[1], in[2]);
+    if (strcmp(op, "dot") == 0) { out[0] = dot(a, V(in[3], in[4], in[5])); return 1; }
+    if (strcmp(op, "normalize") == 0) { v3 r = normalize(a); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 3; }
+    if (strcmp(op, "reflect") == 0) { v3 r = reflect(a, V(in[3], in[4], in[5])); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 3; }
+    if (strcmp(op, "cross") == 0) { v3 r = cross(a, V(in[3], in[4], in[5])); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 3; }
+    if (strcmp(op, "length") == 0) { out[0] = sqrtf(dot(a, a)); return 1; }
+    if (strcmp(op, "mix") == 0) { v3 r = mix3(a, V(in[3], in[4], in[5]), in[6]); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 3; }
+    if (strcmp(op, "mod") == 0) { out[0] = glsl_mod(in[0], in[1]); return 1; }
+    if (strcmp(op, "floor") == 0) { out[0] = floorf(in[0]); return 1; }
+    if (strcmp(op, "inversesqrt") == 0) { out[0] = inversesqrt(in[0]); return 1; }
+    if (strcmp(op, "min") == 0) { out[0] = glsl_min(in[0], in[1]); return 1; }
+    if (strcmp(op, "max") == 0) { out[0] = glsl_max(in[0], in[1]); return 1; }
+    if (strcmp(op, "pow") == 0) { out[0] = rto_powf(in[0], in[1]); return 1; }
+    return -1;
 }
 
 int rto_hit_sphere(const rto_sphere *s, const float o[3], const float d[3],

@@ -11,10 +11,15 @@
  * Pinning: the reference ships no tests or golden images.  The host half is
  * pinned by golden parameter/sphere bytes produced by compiling the
  * reference's own RayTracer.cpp (oracle/_ref).  The integer RNG is pinned by
- * known-answer vectors derived from the shader text.  The floating-point
- * device half cannot be run here (no GLSL compiler, no Vulkan ICD), so for
- * it: PARITY UNPINNED -- the restatement follows the shader source order
- * with every operation rounded once to IEEE-754 binary32 (no contraction).
+ * known-answer vectors derived from the shader text.  The GLSL built-ins the
+ * shader calls (dot, normalize, inversesqrt, reflect, mix, mod, floor, min,
+ * max) are pinned bit for bit by vectors computed with the reference's
+ * vendored GLM 1.0.1 (oracle/ref_glm_probe.cpp, tests/golden/glm_builtins.json).
+ * The shader as a whole cannot be run here (no GLSL compiler, no Vulkan ICD),
+ * so for the composition of those pieces -- control flow, operand order of
+ * the shader's own expressions, pow -- it remains: PARITY UNPINNED.  The
+ * restatement follows the shader source order with every operation rounded
+ * once to IEEE-754 binary32 (no contraction).
  *
  * Arithmetic conventions (GLSL built-ins are restated, see rt_oracle.c):
  *   dot(a,b)        = (a.x*b.x + a.y*b.y) + a.z*b.z
@@ -98,6 +103,10 @@ void rto_default_scene(rto_sphere out[5]);
 /* glm::normalize, as setCamera applies to the direction it stores
  * (src/rt/RayTracer.cpp:301). */
 void rto_normalize3(const float in[3], float out[3]);
+/* The GLSL built-ins as this restatement implements them, by name ("dot", "normalize", "reflect",
+ * "cross", "length", "mix", "mod", "floor", "inversesqrt", "min", "max", "pow"): inputs in `in`
+ * (vectors first, then scalars), results in `out`; returns the number of results or -1. */
+int rto_builtin(const char *op, const float *in, float *out);
 
 /* src/rt/RayTracer.cpp:140-177; dir is the stored camera direction (already
  * normalised once by create() or setCamera()); it is normalised once more

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/host_params.json and tests/golden/rng_kat.json.
+"""Generates tests/golden/host_params.json, tests/golden/rng_kat.json and tests/golden/glm_builtins.json.
 
 host_params.json: GPUSphere / GPUParams bytes printed by oracle/_ref/ref_params_probe, a probe
 linked against the reference's own src/rt/RayTracer.cpp (built by `make -C oracle ref`, only
 possible where /root/reference is mounted).  rng_kat.json: known answers of the shader's integer
 RNG (shaders/raytrace.comp.glsl:37-55) computed here with Python integers, independently of the
-C oracle and of the HIP code.
+C oracle and of the HIP code.  glm_builtins.json: the GLSL built-ins the shader calls (dot,
+normalize, inversesqrt, reflect, mix, mod, floor, min, max, length, cross, pow) evaluated by
+oracle/_ref/ref_glm_probe with the reference's vendored GLM 1.0.1 headers; inputs and results as
+hex words of binary32 values.
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -17,6 +20,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_params_probe")
+GLM_PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_glm_probe")
 
 # name -> probe argv.  "default": create() + setSamplesPerPixel(4) + setAperture(a) as App::run does
 # (src/core/App.cpp:153-156); otherwise: width height aperture vfov focus pos dir through the setters.
@@ -78,15 +82,27 @@ def rng_kat():
     return out
 
 
+def glm_builtins():
+    out = []
+    for line in subprocess.check_output([GLM_PROBE], text=True).splitlines():
+        left, right = line.split("->")
+        parts = left.split()
+        out.append({"op": parts[0], "in": parts[1:], "out": right.split()})
+    return out
+
+
 def main():
-    if not os.path.exists(PROBE):
+    if not os.path.exists(PROBE) or not os.path.exists(GLM_PROBE):
         sys.exit("build oracle/_ref first: make -C oracle ref (needs /root/reference)")
     params = {name: run_probe(args) for name, args in CASES.items()}
     with open(os.path.join(HERE, "host_params.json"), "w") as f:
         json.dump(params, f, indent=1, sort_keys=True)
     with open(os.path.join(HERE, "rng_kat.json"), "w") as f:
         json.dump(rng_kat(), f, indent=1)
-    print("wrote host_params.json (%d cases) and rng_kat.json" % len(params))
+    vectors = glm_builtins()
+    with open(os.path.join(HERE, "glm_builtins.json"), "w") as f:
+        json.dump(vectors, f, separators=(",", ":"))
+    print("wrote host_params.json (%d cases), rng_kat.json and glm_builtins.json (%d vectors)" % (len(params), len(vectors)))
 
 
 if __name__ == "__main__":

@@ -362,14 +362,24 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
 
     // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
     // accumulator in frame order afterwards; the frames of one call are split into groups so that
-    // this image stays within a budget (4 GiB unless RT_PARTIAL_BYTES says otherwise).
+    // this image stays within a budget: 16 GiB (a 64-frame batch at 3840x2160 is 8.5 GB and should
+    // stay one launch on a 288 GB device), at most a quarter of the memory that is free when the
+    // buffer has to grow, or what RT_PARTIAL_BYTES says.
     const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
     const size_t frame_bytes = image_pixels * sizeof(float4);
     uint32_t group = n_frames;
     if (n_frames > 1) {
-        size_t budget = static_cast<size_t>(4) << 30;
+        size_t budget = static_cast<size_t>(16) << 30;
         if (const char* e = std::getenv("RT_PARTIAL_BYTES")) {
             budget = static_cast<size_t>(std::strtoull(e, nullptr, 10));
+        }
+        if (static_cast<size_t>(n_frames) * frame_bytes > h->partial_bytes) {
+            size_t free_bytes = 0, total_bytes = 0;
+            if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+                budget = std::min(budget, std::max(h->partial_bytes, (free_bytes + h->partial_bytes) / 4));
+            } else {
+                (void)hipGetLastError();
+            }
         }
         const size_t fit = std::max<size_t>(2, budget / frame_bytes);
         group = static_cast<uint32_t>(std::min<size_t>(n_frames, fit));

@@ -43,7 +43,7 @@ def main():
         t.render_frames(0, frames)
         t.synchronize()
         wall = time.perf_counter() - t0
-        launches = max(1, -(-frames * w * h * 16 // (4 << 30))) if frames > 1 else 1
+        launches = max(1, -(-frames * w * h * 16 // (16 << 30))) if frames > 1 else 1
         kernel_ms = sum(t.kernel_ms(i) for i in range(launches))
         samples = w * h * spp * frames
         out[name] = {"samples": samples, "kernel_ms": kernel_ms, "wall_ms": wall * 1e3,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the traced path: path samples/sec at 1080p, depth 8.
 
-One "step" renders the batch BASELINE.json quotes the metric on: the default five-sphere scene at
+One "step" renders the batch the headline metric is quoted on: the default five-sphere scene at
 1920x1080, 16 samples per pixel per frame, depth 8, depth of field off, 64 accumulated frames
 (2.12e9 path samples) -- one launch of the trace kernel per rank.  With --gpus N > 1 the frame
 indices are interleaved over the ranks (each rank still renders 64 frames of the full image, i.e.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the BASELINE.json configurations on one GPU (kernel time by HIP events, inputs resident).
+"""Times the benchmark configurations C1..C5 on one GPU (kernel time by HIP events, inputs resident).
 Usage (GPU box): python tools/run_configs.py [c1 c2 c3 c4 c5 ...]"""
 import json
 import os

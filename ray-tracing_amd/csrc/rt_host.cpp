@@ -383,16 +383,28 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         }
         const size_t fit = std::max<size_t>(2, budget / frame_bytes);
         group = static_cast<uint32_t>(std::min<size_t>(n_frames, fit));
-        const size_t need = static_cast<size_t>(group) * frame_bytes;
-        if (need > h->partial_bytes) {
+        if (static_cast<size_t>(group) * frame_bytes > h->partial_bytes) {
             RT_HIP_TRY(h, hipStreamSynchronize(stream));
             if (h->partial) {
                 (void)hipFree(h->partial);
                 h->partial = nullptr;
                 h->partial_bytes = 0;
             }
-            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->partial), need));
-            h->partial_bytes = need;
+            // an allocation that does not fit is retried with half the frames, down to two
+            for (;;) {
+                const size_t need = static_cast<size_t>(group) * frame_bytes;
+                const hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->partial), need);
+                if (e == hipSuccess) {
+                    h->partial_bytes = need;
+                    break;
+                }
+                h->partial = nullptr;
+                if (e != hipErrorOutOfMemory || group <= 2) {
+                    return fail_hip(h, e, "hipMalloc(per-frame sums)", __FILE__, __LINE__);
+                }
+                (void)hipGetLastError();
+                group = std::max(2u, group / 2u);
+            }
         }
     }
     // Unit geometry (frames pooled per unit, pixel tile): defaults are chosen by launch_trace;

@@ -4,7 +4,7 @@ optionally, the linear accumulator (npz).
 
   python tools/render.py out.png [--scene default|random|synthetic4096|FILE] [--size 1280x720]
          [--spp 16] [--depth 8] [--aperture 0.05] [--fov 20] [--frames 16]
-         [--camera px,py,pz --look dx,dy,dz [--focus f]] [--accum out.npz]
+         [--camera=px,py,pz --look=dx,dy,dz [--focus f]] [--accum out.npz]   (use = so that negative numbers are not taken for options)
 """
 import argparse
 import os

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         const bool path_done = !live || miss;
         bool regen = path_done;
         // (not with the hierarchy: there a waiting lane idles through a walk of a hundred nodes, which
-        // costs more than the blocks it would share are worth -- measured 63.5 against 57.9 ms)
+        // costs more than the blocks it would share are worth -- measured 65.3 against 62.4 ms on one box)
         if (kRegenQuorum != 0u && MODE != kTree) {
             const unsigned long long done_mask = __ballot(path_done);
             const unsigned long long in_loop = __ballot(true);

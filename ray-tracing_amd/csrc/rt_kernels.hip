@@ -531,29 +531,30 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             f3 sky = mk(omt + 0.5f * t, omt + 0.7f * t, omt + 1.0f * t);
             f3 radiance = mk(0.0f, 0.0f, 0.0f) + throughput * sky;
             frame_sum = frame_sum + radiance; // :330
-        } else if (is_lambert) {
-            // scatterLambert, :155-174
-            st.section(ST_LAMBERT);
-            f3 target = p + n + unit;
-            ro = p + n * 0.001f;
-            rd = target - p;
-            pending_norm = true; // normalize(target - p) at the top of the next iteration
-            if (flags > 0.5f) {
-                st.section(ST_CHECKER);
-                float checker_index = floorf(p.x) + floorf(p.z);
-                float checker = checker_index - 2.0f * floorf(checker_index / 2.0f);
-                float tone = (checker < 1.0f) ? 0.05f : 0.95f;
-                albedo = albedo * tone;
+        } else if (want3) {
+            if (is_lambert) {
+                // scatterLambert, :155-174
+                st.section(ST_LAMBERT);
+                f3 target = p + n + unit;
+                rd = target - p;
+                pending_norm = true; // normalize(target - p) at the top of the next iteration
+                if (flags > 0.5f) {
+                    st.section(ST_CHECKER);
+                    float checker_index = floorf(p.x) + floorf(p.z);
+                    float checker = checker_index - 2.0f * floorf(checker_index / 2.0f);
+                    float tone = (checker < 1.0f) ? 0.05f : 0.95f;
+                    albedo = albedo * tone;
+                }
+            } else {
+                // scatterMetal, :199-208
+                st.section(ST_METAL);
+                f3 reflected = reflect(unit, n);
+                rd = reflected + ris * fuzz;
+                scattered = dot(rd, n) > 0.0f;
             }
-            throughput = throughput * albedo;
-        } else if (is_metal) {
-            // scatterMetal, :199-208
-            st.section(ST_METAL);
-            f3 reflected = reflect(unit, n);
+            // common to both: origin p + 0.001 n (:160, :203) and attenuation = albedo (:170, :206)
             ro = p + n * 0.001f;
-            rd = reflected + ris * fuzz;
             throughput = throughput * albedo;
-            scattered = dot(rd, n) > 0.0f;
         } else if (hit) {
             // scatterDielectric, :210-234
             st.section(ST_DIEL);

@@ -256,9 +256,68 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
     }
 }
 
+// A unit of work: a pixel tile x a chunk of frames, pooled by one wave.  Its description lives in
+// LDS behind the wave's hash tables (it is only needed when a lane decodes a new item, and scalar
+// registers are scarce in the trace loop); only the item count stays in a register.
+struct Unit {
+    uint32_t x0, y0;         // first pixel of the tile
+    uint32_t tile_w, tile_h; // :302-305 bounds (ragged right/bottom edges)
+    uint32_t tile_pixels;
+    uint32_t rel_begin;      // first frame of the chunk, relative to first_frame
+    uint32_t n_items;
+};
+constexpr uint32_t kUnitWords = 80; // offset of the unit description in a wave's table
+constexpr uint32_t kWaveTableWords = 88;
+
+// Unit number `unit` (chunk-major) of the launch, and the wave's tables of the hash terms of :37-44
+// for its columns, rows and frames (the seed of an item is hash(px) ^ hash(py) ^ hash(frame),
+// :310-311).  Every lane of the wave has to be active.
+__device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, uint32_t unit, uint32_t* hash_tab)
+{
+    // The launch geometry is read from the kernel-argument segment again (the struct is the kernel's
+    // only argument) instead of being kept in scalar registers through the whole trace loop, which
+    // is short of them; the empty asm keeps the compiler from recognising the copy.
+    (void)A_in_registers;
+    const void* segment = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(segment));
+    const TraceArgs& A = *reinterpret_cast<const TraceArgs*>(segment);
+    Unit u;
+    const uint32_t chunk = unit / A.n_tiles;
+    const uint32_t tile = unit - chunk * A.n_tiles;
+    const uint32_t tile_y = tile / A.tiles_x;
+    const uint32_t tile_x = tile - tile_y * A.tiles_x;
+    // the pixel tile of a unit is 2^tile_w_log2 x 2^tile_h_log2, at most 8 x 8
+    u.x0 = tile_x << A.tile_w_log2;
+    u.y0 = A.row_begin + (tile_y << A.tile_h_log2);
+    u.tile_w = min(1u << A.tile_w_log2, A.width - u.x0);
+    u.tile_h = min(1u << A.tile_h_log2, A.row_end - u.y0);
+    u.tile_pixels = u.tile_w * u.tile_h;
+    u.rel_begin = chunk * A.frames_per_unit;
+    const uint32_t rel_count = min(A.frames_per_unit, A.n_frames - u.rel_begin);
+    u.n_items = u.tile_pixels * rel_count;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane < 16u) {
+        hash_tab[lane] = hash1(lane < 8u ? u.x0 + lane : u.y0 + lane - 8u);
+    }
+    if (lane < rel_count) {
+        hash_tab[16u + lane] = hash1(A.first_frame + (u.rel_begin + lane) * A.frame_stride);
+    }
+    if (lane == 0u) {
+        hash_tab[kUnitWords + 0u] = u.x0;
+        hash_tab[kUnitWords + 1u] = u.y0;
+        hash_tab[kUnitWords + 2u] = u.tile_w;
+        hash_tab[kUnitWords + 3u] = u.tile_h;
+        hash_tab[kUnitWords + 4u] = u.tile_pixels;
+        hash_tab[kUnitWords + 5u] = u.rel_begin;
+    }
+    return u.n_items;
+}
+
 // BLOCK = threads per workgroup: 256 for scenes whose whole records fit in LDS, 512 for the
 // geometry-only layout (64 KiB of LDS per workgroup: two workgroups, 16 waves, per CU); the
 // hierarchy uses 256, 512 or 1024 depending on its size.
+// One unit per wave: the launch has as many waves as units.  (Persistent waves that take their next
+// unit from a counter in memory when their pool runs dry were measured 2.8 % slower.)
 template <int MODE, class Stats, int BLOCK>
 __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
@@ -276,38 +335,18 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
     uint32_t* hash_tab = (MODE == kTree ? node_word + lds_records
                                         : reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 3u : 1u) * sphere_count)) +
-                         (threadIdx.x >> 6) * 80u;
+                         (threadIdx.x >> 6) * kWaveTableWords;
 
     Stats st;
 
-    // ---- this wave's unit: (tile, frame chunk), chunk-major ----
+    // ---- this wave's (first) unit ----
     const uint32_t n_units = A.n_tiles * A.n_chunks;
-    const uint32_t unit = min(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), n_units - 1u);
-    const bool spare_wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6) >= n_units;
-    const uint32_t chunk = unit / A.n_tiles;
-    const uint32_t tile = unit - chunk * A.n_tiles;
-    const uint32_t tile_y = tile / A.tiles_x;
-    const uint32_t tile_x = tile - tile_y * A.tiles_x;
-    // the pixel tile of a unit is 2^tile_w_log2 x 2^tile_h_log2, at most 8 x 8
+    const uint32_t wave_index = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t first_unit = wave_index;
+    const bool spare_wave = first_unit >= n_units;
     const uint32_t full_w = 1u << A.tile_w_log2, full_h = 1u << A.tile_h_log2;
-    const uint32_t x0 = tile_x << A.tile_w_log2;
-    const uint32_t y0 = A.row_begin + (tile_y << A.tile_h_log2);
-    const uint32_t tile_w = min(full_w, A.width - x0);    // :302-305 bounds (ragged right/bottom edges)
-    const uint32_t tile_h = min(full_h, A.row_end - y0);
-    const uint32_t tile_pixels = tile_w * tile_h;
-    const uint32_t rel_begin = chunk * A.frames_per_unit;
-    const uint32_t rel_count = min(A.frames_per_unit, A.n_frames - rel_begin);
-    const uint32_t n_items = tile_pixels * rel_count;
+    const uint32_t n_items = load_unit(A, min(first_unit, n_units - 1u), hash_tab);
     uint32_t next_item = 0; // wave-uniform pool cursor
-    {
-        const uint32_t lane = threadIdx.x & 63u;
-        if (lane < 16u) {
-            hash_tab[lane] = hash1(lane < 8u ? x0 + lane : y0 + lane - 8u);
-        }
-        if (lane < rel_count) {
-            hash_tab[16u + lane] = hash1(A.first_frame + (rel_begin + lane) * A.frame_stride);
-        }
-    }
     // both end with the workgroup barrier
     if (MODE == kTree) {
         stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, geom, node_word);
@@ -445,6 +484,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         const bool exiting = need_item && my_item >= n_items; // pool drained: leave after the write-out
         if (need_item && !exiting) {
             st.section(ST_ITEM);
+            const uint32_t unit_x0 = hash_tab[kUnitWords + 0u], unit_y0 = hash_tab[kUnitWords + 1u];
+            const uint32_t tile_w = hash_tab[kUnitWords + 2u];
+            const uint32_t tile_pixels = hash_tab[kUnitWords + 4u], rel_begin = hash_tab[kUnitWords + 5u];
             uint32_t frame_in_chunk, pix;
             if (tile_pixels == full_w * full_h) {
                 frame_in_chunk = my_item >> (A.tile_w_log2 + A.tile_h_log2);
@@ -461,8 +503,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 ly = pix / tile_w;
                 lx = pix - ly * tile_w;
             }
-            const uint32_t px = x0 + lx;
-            const uint32_t py = y0 + ly;
+            const uint32_t px = unit_x0 + lx;
+            const uint32_t py = unit_y0 + ly;
             rel = rel_begin + frame_in_chunk;
             texel = py * A.width + px;
             fpx = (float)(int32_t)px;
@@ -751,7 +793,7 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
         *mat_in_lds = full;
     }
     // scene records + 80 hash words for each of up to 8 waves
-    return (size_t)sphere_count * (full ? 48u : 16u) + 8u * 80u * 4u;
+    return (size_t)sphere_count * (full ? 48u : 16u) + 8u * kWaveTableWords * 4u;
 }
 
 namespace {
@@ -816,11 +858,11 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         // of LDS still hold 16 to 20 waves
         const size_t nodes_bytes = (size_t)args.tree_nodes * 20u;
         if (nodes_bytes <= 30u * 1024u) {
-            launch_trace_as<kTree, 256>(args, units, nodes_bytes + 4u * 80u * 4u, stream);
+            launch_trace_as<kTree, 256>(args, units, nodes_bytes + 4u * kWaveTableWords * 4u, stream);
         } else if (nodes_bytes <= 72u * 1024u) {
-            launch_trace_as<kTree, 512>(args, units, nodes_bytes + 8u * 80u * 4u, stream);
+            launch_trace_as<kTree, 512>(args, units, nodes_bytes + 8u * kWaveTableWords * 4u, stream);
         } else {
-            launch_trace_as<kTree, 1024>(args, units, nodes_bytes + 16u * 80u * 4u, stream);
+            launch_trace_as<kTree, 1024>(args, units, nodes_bytes + 16u * kWaveTableWords * 4u, stream);
         }
         return hipGetLastError();
     }

@@ -269,18 +269,24 @@ struct Unit {
 constexpr uint32_t kUnitWords = 80; // offset of the unit description in a wave's table
 constexpr uint32_t kWaveTableWords = 88;
 
+// The kernel's argument struct as it lies in the kernel-argument segment (it is the only argument).
+// Blocks that run rarely read what they need from there instead of keeping it in scalar registers
+// through the whole trace loop, which is short of them; the empty asm keeps the compiler from
+// recognising the copy.
+__device__ __forceinline__ const TraceArgs& args_in_memory()
+{
+    const void* segment = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(segment));
+    return *reinterpret_cast<const TraceArgs*>(segment);
+}
+
 // Unit number `unit` (chunk-major) of the launch, and the wave's tables of the hash terms of :37-44
 // for its columns, rows and frames (the seed of an item is hash(px) ^ hash(py) ^ hash(frame),
 // :310-311).  Every lane of the wave has to be active.
 __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, uint32_t unit, uint32_t* hash_tab)
 {
-    // The launch geometry is read from the kernel-argument segment again (the struct is the kernel's
-    // only argument) instead of being kept in scalar registers through the whole trace loop, which
-    // is short of them; the empty asm keeps the compiler from recognising the copy.
     (void)A_in_registers;
-    const void* segment = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(segment));
-    const TraceArgs& A = *reinterpret_cast<const TraceArgs*>(segment);
+    const TraceArgs& A = args_in_memory();
     Unit u;
     const uint32_t chunk = unit / A.n_tiles;
     const uint32_t tile = unit - chunk * A.n_tiles;
@@ -360,7 +366,6 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t spp_raw = A.params.frame_sample_depth_count[1];
     const uint32_t spp = spp_raw > 1u ? spp_raw : 1u; // :308
     const uint32_t max_depth = A.params.frame_sample_depth_count[2];
-    const size_t image_pixels = (size_t)A.width * A.height;
 
     const f3 origin = mk(A.params.origin_lens[0], A.params.origin_lens[1], A.params.origin_lens[2]);
     const float lens_radius = A.params.origin_lens[3];
@@ -474,8 +479,11 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         const bool write_out = need_item && has_item;
         const uint32_t old_texel = texel;
         const uint32_t old_rel = rel;
-        if (write_out && A.rng_out != nullptr && rel + 1u == A.n_frames) {
-            A.rng_out[texel] = rng;
+        if (write_out) {
+            const TraceArgs& M = args_in_memory();
+            if (M.rng_out != nullptr && rel + 1u == M.n_frames) {
+                M.rng_out[texel] = rng;
+            }
         }
         // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
         const unsigned long long want = __ballot(need_item);
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             const uint32_t px = unit_x0 + lx;
             const uint32_t py = unit_y0 + ly;
             rel = rel_begin + frame_in_chunk;
-            texel = py * A.width + px;
+            texel = py * args_in_memory().width + px;
             fpx = (float)(int32_t)px;
             fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
             rng = hash_tab[lx] ^ hash_tab[8u + ly] ^ hash_tab[16u + frame_in_chunk]; // :310-311
@@ -628,16 +636,17 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         st.phase_end(PH_SHADE);
         // ------------------------------------------------------------------ finished item, :333-335
         if (write_out) {
-            if (A.partial != nullptr) {
-                A.partial[(size_t)old_rel * image_pixels + old_texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
+            const TraceArgs& M = args_in_memory();
+            if (M.partial != nullptr) {
+                M.partial[(size_t)old_rel * ((size_t)M.width * M.height) + old_texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
             } else {
-                const float4 prev = A.accum[old_texel];
+                const float4 prev = M.accum[old_texel];
                 const f3 total = mk(prev.x, prev.y, prev.z) + frame_sum;
-                A.accum[old_texel] = make_float4(total.x, total.y, total.z, 1.0f);
-                if (A.output != nullptr) {
+                M.accum[old_texel] = make_float4(total.x, total.y, total.z, 1.0f);
+                if (M.output != nullptr) {
                     // :337 (frame + 1u) * spp wraps in uint32 before the conversion
-                    const uint32_t frame = A.first_frame + old_rel * A.frame_stride;
-                    A.output[old_texel] = tonemap_rgba8(total, (float)((frame + 1u) * spp_raw));
+                    const uint32_t frame = M.first_frame + old_rel * M.frame_stride;
+                    M.output[old_texel] = tonemap_rgba8(total, (float)((frame + 1u) * M.params.frame_sample_depth_count[1]));
                 }
             }
             frame_sum = mk(0.0f, 0.0f, 0.0f);

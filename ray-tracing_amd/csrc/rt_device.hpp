@@ -150,6 +150,14 @@ __device__ __forceinline__ float rnd(uint32_t& state)
 {
     return (float)(lcg(state) & 0x00FFFFFFu) * 5.9604644775390625e-08f;
 }
+// base + rand(state) in one instruction.  Multiplying the 24-bit integer by 2^-24 is exact, so the
+// fused multiply-add rounds the same real number as the separate addition does.  (The same holds
+// wherever this file or the kernel fuses a product with a power of two; products that round are
+// never fused.)
+__device__ __forceinline__ float rnd_plus(uint32_t& state, float base)
+{
+    return __builtin_fmaf((float)(lcg(state) & 0x00FFFFFFu), 5.9604644775390625e-08f, base);
+}
 
 // ---------------------------------------------------------------- pow
 // GLSL pow(x,y) inherits its precision from exp2(y*log2(x)).  These kernels use

@@ -528,8 +528,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         if (gen) {
             st.section(ST_GEN);
             --samples_left;
-            u_coord = (fpx + rnd(rng)) * inv_w;
-            v_coord = (fpy_flipped + rnd(rng)) * inv_h;
+            u_coord = rnd_plus(rng, fpx) * inv_w;
+            v_coord = rnd_plus(rng, fpy_flipped) * inv_h;
         }
 
         st.phase_end(PH_ITEM);
@@ -576,10 +576,14 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         if (miss) {
             // sky, :261-269
             st.section(ST_SKY);
-            float t = 0.5f * (unit.y + 1.0f);
+            // Three exact rewrites with fused multiply-adds (one rounding of the same real number each):
+            // 0.5 * (y + 1) = fma(0.5, y, 0.5) because halving commutes with the rounding of y + 1;
+            // 0.5 * t is exact; and 0 + throughput * sky = fma(throughput, sky, +0).
+            float t = __builtin_fmaf(0.5f, unit.y, 0.5f);
             float omt = 1.0f - t;
-            f3 sky = mk(omt + 0.5f * t, omt + 0.7f * t, omt + 1.0f * t);
-            f3 radiance = mk(0.0f, 0.0f, 0.0f) + throughput * sky;
+            f3 sky = mk(__builtin_fmaf(0.5f, t, omt), omt + 0.7f * t, omt + 1.0f * t);
+            f3 radiance = mk(__builtin_fmaf(throughput.x, sky.x, 0.0f), __builtin_fmaf(throughput.y, sky.y, 0.0f),
+                             __builtin_fmaf(throughput.z, sky.z, 0.0f));
             frame_sum = frame_sum + radiance; // :330
         } else if (want3) {
             if (is_lambert) {
@@ -591,7 +595,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 if (flags > 0.5f) {
                     st.section(ST_CHECKER);
                     float checker_index = floorf(p.x) + floorf(p.z);
-                    float checker = checker_index - 2.0f * floorf(checker_index / 2.0f);
+                    // mod(x, 2) = x - 2 * floor(x / 2); halving and doubling are exact, so this rounds once like the original
+                    float checker = __builtin_fmaf(-2.0f, floorf(checker_index * 0.5f), checker_index);
                     float tone = (checker < 1.0f) ? 0.05f : 0.95f;
                     albedo = albedo * tone;
                 }

@@ -553,16 +553,28 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             const uint32_t add3 = is3 & 1013904223u;
             const uint32_t mask3 = is3 & 0x00FFFFFFu;
             const int32_t off3 = (int32_t)(is3 & 0x00800000u);
-            do {
-                st.section(ST_RIS_IT);
-                const uint32_t s1 = 1664525u * rng + 1013904223u;
-                const uint32_t s2 = 1664525u * s1 + 1013904223u;
-                rng = mul3 * s2 + add3;
-                mx = (float)((int32_t)(s1 & 0x00FFFFFFu) - 0x00800000);
-                my = (float)((int32_t)(s2 & 0x00FFFFFFu) - 0x00800000);
-                mz = (float)((int32_t)(rng & mask3) - off3);
-                m_dot = (mx * mx + my * my) + mz * mz;
-            } while (m_dot >= 0x1p46f);
+            if (__ballot(want3) == 0ull) {
+                // only camera lanes in this wave (a tile of sky, typically): two draws per candidate
+                do {
+                    st.section(ST_DISK_IT);
+                    const uint32_t s1 = 1664525u * rng + 1013904223u;
+                    rng = 1664525u * s1 + 1013904223u;
+                    mx = (float)((int32_t)(s1 & 0x00FFFFFFu) - 0x00800000);
+                    my = (float)((int32_t)(rng & 0x00FFFFFFu) - 0x00800000);
+                    m_dot = mx * mx + my * my;
+                } while (m_dot >= 0x1p46f);
+            } else {
+                do {
+                    st.section(ST_RIS_IT);
+                    const uint32_t s1 = 1664525u * rng + 1013904223u;
+                    const uint32_t s2 = 1664525u * s1 + 1013904223u;
+                    rng = mul3 * s2 + add3;
+                    mx = (float)((int32_t)(s1 & 0x00FFFFFFu) - 0x00800000);
+                    my = (float)((int32_t)(s2 & 0x00FFFFFFu) - 0x00800000);
+                    mz = (float)((int32_t)(rng & mask3) - off3);
+                    m_dot = (mx * mx + my * my) + mz * mz;
+                } while (m_dot >= 0x1p46f);
+            }
         }
         const f3 ris = mk(mx * 0x1p-23f, my * 0x1p-23f, mz * 0x1p-23f);
         st.phase_end(PH_SAMPLER);

@@ -193,6 +193,7 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
         if (rden.bounded) {
             const uint32_t end = A.tree_nodes * 16u;
             uint32_t at = 0; // byte offset of this lane's node
+            float beyond_limit = __builtin_inff(); // 2.5 * dot(d,d) * closest^2
             while (at < end) {
                 st.section(ST_NODE);
                 const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + at);
@@ -201,10 +202,14 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
                 const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
                 const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, rden.a, k);
                 uint32_t next = at + 16u;
-                if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c)) {
+                // A ball (radius R, centre at distance D from the origin) lies wholly beyond the closest
+                // hit so far when D > L + R, L = closest * |d|; D^2 - 2 R^2 > 2.5 L^2 implies D > 1.05 (L + R),
+                // which no rounding here comes near, so every root inside the ball exceeds `closest`.
+                if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > beyond_limit) {
                     next = w & kTreeOffsetMask;
                 } else if ((int32_t)w < 0) {
                     sphere_closest_any_order(q, rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), closest, best, st);
+                    beyond_limit = 2.5f * rden.a * closest * closest;
                 }
                 at = next;
             }

@@ -19,6 +19,14 @@
 //    skipped as well: every sphere inside the ball meets the line only at parameters below
 //    -0.05 |oc| / |d|, far further from zero than the rounding of the roots (below 0.003 |oc| / |d|),
 //    so both roots come out negative and :125-131 reject them.
+//  * A ball (centre at distance D from the origin, radius R; a leaf's own sphere or a node's ball)
+//    is also left out when it lies wholly beyond the closest hit found so far, L = closest * |d|
+//    away.  The walk tests (k D^2 - w) - w > 2.5 a closest^2 with the values it has anyway, i.e.
+//    D^2 - 2.25 R^2 > 2.5 L^2 for a node and D^2 - 2 r^2 > 2.5 L^2 for a leaf, up to a relative 2^-13.
+//    Since 2 r^2 + 2.5 L^2 >= 1.11 (L + r)^2, that gives D > 1.05 (L + R): every point of the ball is
+//    more than 1.05 L + 0.05 R from the origin, while the computed roots of a sphere inside it are
+//    off by less than 0.003 (D + R) / |d| even for a grazing hit.  So both roots exceed `closest`
+//    and :125-131 would reject them (an equal root, which replaces an earlier sphere, cannot occur).
 #include "rt_tree.hpp"
 
 #include <algorithm>

@@ -229,6 +229,86 @@ def test_no_accepted_sphere_is_skipped(pkg, name):
     assert reached < 0.2 * rays * len(scene)       # and the walk does prune
 
 
+def _roots(hb, disc, a, tmin, tmax):
+    """The root hitSphere accepts inside [tmin, tmax] (near first, then far) and whether there is one."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        sq = np.sqrt(np.where(disc < F(0.0), F(0.0), disc))
+        near = (-hb - sq) / a
+        far = (-hb + sq) / a
+    near_out = (near < tmin) | (near > tmax)
+    far_out = (far < tmin) | (far > tmax)
+    root = np.where(near_out, far, near)
+    return root, ~(disc < F(0.0)) & ~(near_out & far_out)
+
+
+def _walk_closest(geom, word, o, d):
+    """The kernel's walk in float32 for every ray at once, with its running `closest` and the test that
+    leaves out balls lying wholly beyond it; returns (closest, index of the winning sphere or -1)."""
+    n = len(word)
+    rays = o.shape[0]
+    a = _dot(d, d)
+    at = np.zeros(rays, dtype=np.int64)
+    leaf = (word & LEAF) != 0
+    skip = (word & 0x1FFFF).astype(np.int64) // 16
+    sphere = ((word & 0x7FFFFFFF) >> 17).astype(np.int64)
+    closest = np.full(rays, 1e20, dtype=np.float32)
+    best = np.full(rays, -1, dtype=np.int64)
+    limit = np.full(rays, np.inf, dtype=np.float32)
+    visits = 0
+    for _ in range(n + 1):
+        live = at < n
+        if not live.any():
+            break
+        visits += int(live.sum())
+        idx = np.where(live, at, 0)
+        scale = np.where(leaf[idx], F(1.0), KEEP).astype(np.float32)
+        hb, c, disc = _quadratic(geom[idx, :3], geom[idx, 3], o, d, a, scale)
+        with np.errstate(invalid="ignore", over="ignore"):
+            ok = _passes(hb, c, disc) & ~(c - geom[idx, 3] > limit)
+            root, found = _roots(hb, disc, a, F(0.001), closest)
+            take = live & ok & leaf[idx] & found & ((root < closest) | (sphere[idx] > best))
+            closest = np.where(take, root, closest)
+            best = np.where(take, sphere[idx], best)
+            limit = np.where(take, F(2.5) * a * closest * closest, limit)
+        at = np.where(live, np.where(ok, at + 1, skip[idx]), at)
+    else:
+        raise AssertionError("a traversal did not terminate")
+    return closest, best, visits
+
+
+@pytest.mark.parametrize("name", ["synthetic4096", "random", "clusters"])
+def test_walk_finds_the_hit_of_the_loop_over_all_spheres(pkg, name):
+    """The walk, with the balls beyond the running closest hit left out, ends with the same root and the
+    same sphere as the loop of :247-259 (smallest accepted root; of equal roots the highest index)."""
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "random": pkg.random_scene,
+             "clusters": lambda: _cluster_scene(pkg)}[name]()
+    t = _host(pkg, scene)
+    geom, word = t.get_scene_hierarchy()
+    t.destroy()
+    rays = 1500 if name == "synthetic4096" else 3000
+    o, d = _rays(scene, rays, seed=23)
+    a = _dot(d, d)
+    closest, best, visits = _walk_closest(geom, word, o, d)
+    centre = scene[:, :3]
+    r2 = scene[:, 3] * scene[:, 3]
+    hits = 0
+    for lo in range(0, rays, 250):
+        sl = slice(lo, lo + 250)
+        hb, c, disc = _quadratic(centre[None, :, :], r2[None, :], o[sl, None, :], d[sl, None, :], a[sl, None], F(1.0))
+        root, found = _roots(hb, disc, a[sl, None], F(0.001), F(1e20))
+        root = np.where(found, root, F(np.inf))
+        want_closest = root.min(axis=1)
+        any_hit = np.isfinite(want_closest)
+        ties = root == want_closest[:, None]
+        want_best = np.where(any_hit, len(scene) - 1 - np.argmax(ties[:, ::-1], axis=1), -1)
+        want_closest = np.where(any_hit, want_closest, F(1e20)).astype(np.float32)
+        assert np.array_equal(best[sl], want_best)
+        assert np.array_equal(closest[sl].view(np.uint32), want_closest.view(np.uint32))
+        hits += int(any_hit.sum())
+    assert hits > rays // 2
+    assert visits < 0.25 * rays * len(word)    # node visits, inner nodes included
+
+
 # ---------------------------------------------------------------------------------------- GPU
 def _render(pkg, scene, hierarchy, w=160, h=96, spp=4, depth=12, frames=3, camera=None, focus=6.0, aperture=0.05):
     t = pkg.RayTracer().create(w, h, device_id=0)

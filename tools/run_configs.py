@@ -20,6 +20,7 @@ CONFIGS = {
     "c5": (1920, 1080, 16, 50, 0.05, 1, "synthetic4096"),
     "c5s": (480, 270, 16, 50, 0.05, 1, "synthetic4096"),
     "c5m": (960, 540, 16, 50, 0.05, 4, "synthetic4096"),
+    "rnd": (1920, 1080, 16, 50, 0.1, 4, "random"),       # the ~480-sphere random scene, camera (13,2,3)
 }
 
 
@@ -37,6 +38,8 @@ def main():
         if scene == "synthetic4096":
             t.set_spheres(pkg.synthetic_scene(4096))
             t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
+        elif scene == "random":
+            t.set_spheres(pkg.random_scene())
         t.render_frames(0, frames)       # warm-up (also allocates the per-frame sum image)
         t.synchronize()
         t0 = time.perf_counter()

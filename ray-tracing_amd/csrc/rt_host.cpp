@@ -49,6 +49,7 @@ struct rt_tracer {
     bool scene_bounded = false;       // every sphere finite, |centre| and |radius| at most 2^20
     float4* d_tree_geom = nullptr;
     uint32_t* d_tree_word = nullptr;
+    uint32_t* d_unit_counter = nullptr;
     uint32_t d_tree_capacity = 0;
 
     bool reset_accum = true;          // mResetAccum
@@ -289,6 +290,9 @@ int upload_scene(rt_tracer* h, hipStream_t stream)
         RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_word), nodes * sizeof(uint32_t)));
         h->d_tree_capacity = nodes;
     }
+    if (nodes != 0 && h->d_unit_counter == nullptr) {
+        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_unit_counter), 256));
+    }
     // pageable-memory copies: each returns once the source has been staged, ordered on the stream
     RT_HIP_TRY(h, hipMemcpyAsync(h->d_spheres, h->spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice, stream));
     if (nodes != 0) {
@@ -437,6 +441,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         const bool tree = h->use_tree && !h->tree.empty();
         args.tree_geom = tree ? h->d_tree_geom : nullptr;
         args.tree_word = tree ? h->d_tree_word : nullptr;
+        args.unit_counter = tree ? h->d_unit_counter : nullptr;
         args.tree_nodes = tree ? h->tree.node_count() : 0u;
         args.scene_bounded = h->scene_bounded ? 1u : 0u;
         args.width = h->width;
@@ -577,6 +582,7 @@ int rt_destroy(rt_handle h)
         if (h->d_spheres) { (void)hipFree(h->d_spheres); }
         if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); }
         if (h->d_tree_word) { (void)hipFree(h->d_tree_word); }
+        if (h->d_unit_counter) { (void)hipFree(h->d_unit_counter); }
         for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
             if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }

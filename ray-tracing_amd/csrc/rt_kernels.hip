@@ -58,6 +58,11 @@ constexpr float kTMin = 0.001f;
 #define RT_REGEN_QUORUM 16
 #endif
 constexpr uint32_t kRegenQuorum = RT_REGEN_QUORUM;
+// Lanes with something else to do that end a round of the hierarchy walk (0 = walk until every lane is done).
+#ifndef RT_WALK_QUORUM
+#define RT_WALK_QUORUM 24
+#endif
+constexpr uint32_t kWalkQuorum = RT_WALK_QUORUM;
 
 // ---- diagnostic section counters -------------------------------------------------------------
 // A diagnostic build (-DRT_STATS) counts, per code section, how often a wave executes it and the
@@ -187,42 +192,6 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
     constexpr bool MAT_IN_LDS = MODE == kFullLds;
     closest = 1e20f;
     best = -1;
-    if (MODE == kTree) {
-        rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
-        // the skip tests of the hierarchy are proven for rays in the bounded range only
-        if (rden.bounded) {
-            const uint32_t end = A.tree_nodes * 16u;
-            uint32_t at = 0; // byte offset of this lane's node
-            float beyond_limit = __builtin_inff(); // 2.5 * dot(d,d) * closest^2
-            while (at < end) {
-                st.section(ST_NODE);
-                const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + at);
-                const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (at >> 2));
-                // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
-                const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
-                const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, rden.a, k);
-                uint32_t next = at + 16u;
-                // A ball (radius R, centre at distance D from the origin) lies wholly beyond the closest
-                // hit so far when D > L + R, L = closest * |d|; D^2 - 2 R^2 > 2.5 L^2 implies D > 1.05 (L + R),
-                // which no rounding here comes near, so every root inside the ball exceeds `closest`.
-                if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > beyond_limit) {
-                    next = w & kTreeOffsetMask;
-                } else if ((int32_t)w < 0) {
-                    sphere_closest_any_order(q, rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), closest, best, st);
-                    beyond_limit = 2.5f * rden.a * closest * closest;
-                }
-                at = next;
-            }
-        } else {
-            RT_COLD_PATH();
-            for (uint32_t i = 0; i < sphere_count; ++i) {
-                const float4 cr = *reinterpret_cast<const float4*>(A.spheres + i);
-                const float4 g = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
-                sphere_closest(sphere_quadratic(g, ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
-            }
-        }
-        return;
-    }
     rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
     uint32_t i = 0;
     if (!MAT_IN_LDS) {
@@ -263,6 +232,72 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
     }
 }
 
+// Walk of the hierarchy, resumable: a lane's search for the closest hit of its segment can stretch
+// over several iterations of the trace loop.  Lanes need walks of very different lengths (66 to 144
+// nodes on the 4096-sphere grid), so instead of letting the whole wave wait for its longest walk the
+// walk loop stops as soon as kWalkQuorum lanes have something else to do (their walk is over, or they
+// carry no ray); those lanes are shaded and given new rays while the others keep their place.
+struct TreeWalk {
+    uint32_t at;         // byte offset of this lane's node; at or past the end of the array: no walk in progress
+    float closest;
+    int best;
+    float beyond_limit;  // 2.5 * dot(d,d) * closest^2
+    RayDenominator rden;
+};
+
+template <class Stats>
+__device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom, const uint32_t* node_word, uint32_t sphere_count,
+                                          bool live, f3 ro, f3 rd, TreeWalk& t, Stats& st)
+{
+    const uint32_t end = A.tree_nodes * 16u;
+    if (live && t.at >= end) {
+        // a new segment
+        t.closest = 1e20f;
+        t.best = -1;
+        t.beyond_limit = __builtin_inff();
+        t.rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
+        // the skip tests of the hierarchy are proven for rays in the bounded range only
+        if (t.rden.bounded) {
+            t.at = 0;
+        } else {
+            RT_COLD_PATH();
+            for (uint32_t i = 0; i < sphere_count; ++i) {
+                const float4 cr = *reinterpret_cast<const float4*>(A.spheres + i);
+                const float4 g = make_float4(cr.x, cr.y, cr.z, cr.w * cr.w);
+                sphere_closest(sphere_quadratic(g, ro, rd, t.rden.a), t.rden, kTMin, (int)i, t.closest, t.best, st);
+            }
+        }
+    }
+    // the round ends when fewer than this many lanes are still walking
+    const uint32_t in_loop = (uint32_t)__popcll(__ballot(true));
+    const uint32_t few = __builtin_amdgcn_readfirstlane(kWalkQuorum != 0u && in_loop > kWalkQuorum ? in_loop - kWalkQuorum : 0u);
+    if ((uint32_t)__popcll(__ballot(t.at < end)) <= few) {
+        return;
+    }
+    // (bottom-tested by hand: the compiler does not rotate a loop whose test holds a ballot)
+    do {
+        if (t.at < end) {
+            st.section(ST_NODE);
+            const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + t.at);
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (t.at >> 2));
+            // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
+            const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
+            const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, t.rden.a, k);
+            uint32_t next = t.at + 16u;
+            // A ball (radius R, centre at distance D from the origin) lies wholly beyond the closest
+            // hit so far when D > L + R, L = closest * |d|; D^2 - 2 R^2 > 2.5 L^2 implies D > 1.05 (L + R),
+            // which no rounding here comes near, so every root inside the ball exceeds `closest`.
+            if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit) {
+                next = w & kTreeOffsetMask;
+            } else if ((int32_t)w < 0) {
+                sphere_closest_any_order(q, t.rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), t.closest, t.best, st);
+                t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
+            }
+            t.at = next;
+        }
+    } while ((uint32_t)__popcll(__ballot(t.at < end)) > few);
+}
+
 // A unit of work: a pixel tile x a chunk of frames, pooled by one wave.  Its description lives in
 // LDS behind the wave's hash tables (it is only needed when a lane decodes a new item, and scalar
 // registers are scarce in the trace loop); only the item count stays in a register.
@@ -285,6 +320,17 @@ __device__ __forceinline__ const TraceArgs& args_in_memory()
     const void* segment = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(segment));
     return *reinterpret_cast<const TraceArgs*>(segment);
+}
+
+// The next unit of the launch for this wave, from the counter the host zeroes before the launch.
+// Every lane of the wave has to be active.
+__device__ __forceinline__ uint32_t next_unit(uint32_t* counter)
+{
+    uint32_t unit = 0;
+    if ((threadIdx.x & 63u) == 0u) {
+        unit = atomicAdd(counter, 1u);
+    }
+    return __builtin_amdgcn_readfirstlane(unit);
 }
 
 // Unit number `unit` (chunk-major) of the launch, and the wave's tables of the hash terms of :37-44
@@ -353,13 +399,18 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     Stats st;
 
     // ---- this wave's (first) unit ----
+    // With the hierarchy a wave takes one unit after another from a counter in memory (walks are long
+    // and uneven, and a workgroup of sixteen waves holds its LDS until its last wave is through);
+    // otherwise there are as many waves as units.
+    constexpr bool PERSISTENT = MODE == kTree;
     const uint32_t n_units = A.n_tiles * A.n_chunks;
     const uint32_t wave_index = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint32_t first_unit = wave_index;
+    const uint32_t first_unit = PERSISTENT ? next_unit(A.unit_counter) : wave_index;
     const bool spare_wave = first_unit >= n_units;
     const uint32_t full_w = 1u << A.tile_w_log2, full_h = 1u << A.tile_h_log2;
-    const uint32_t n_items = load_unit(A, min(first_unit, n_units - 1u), hash_tab);
+    uint32_t n_items = load_unit(A, min(first_unit, n_units - 1u), hash_tab);
     uint32_t next_item = 0; // wave-uniform pool cursor
+    bool more_units = PERSISTENT; // wave-uniform: the counter has not run past the last unit yet
     // both end with the workgroup barrier
     if (MODE == kTree) {
         stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, geom, node_word);
@@ -406,6 +457,16 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     f3 ro = origin, rd = origin;
     f3 throughput = mk(1.0f, 1.0f, 1.0f);
 
+    TreeWalk walk; // kTree only
+    walk.at = 0xFFFFFFFFu;
+    walk.closest = 1e20f;
+    walk.best = -1;
+    walk.beyond_limit = 0.0f;
+    walk.rden.a = 1.0f;
+    walk.rden.rcp_a = 1.0f;
+    walk.rden.a_ok = true;
+    walk.rden.bounded = false;
+
     for (;;) {
         st.section(ST_ITER);
         st.phase_start();
@@ -425,12 +486,19 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         rden.rcp_a = 1.0f;
         rden.a_ok = true;
         rden.bounded = false;
-        if (live) {
+        bool traced = live; // the lane's segment has been searched to its end in this iteration
+        if (MODE == kTree) {
+            tree_walk(A, geom, node_word, sphere_count, live, ro, rd, walk, st);
+            traced = live && walk.at >= A.tree_nodes * 16u;
+            closest = walk.closest;
+            best = traced ? walk.best : -1;
+            rden = walk.rden;
+        } else if (live) {
             closest_hit<MODE>(A, geom, node_word, sphere_count, ro, rd, rden, closest, best, st);
         }
         st.phase_end(PH_INTERSECT);
-        const bool hit = best >= 0; // only live lanes can hit
-        const bool miss = live && !hit;
+        const bool hit = best >= 0; // only lanes whose segment has been searched can hit
+        const bool miss = traced && !hit;
 
         // ------------------------------------------------------------------ winner's record, :135-149
         f3 p, n, albedo; // defined for hit lanes only
@@ -494,10 +562,27 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         }
         // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
         const unsigned long long want = __ballot(need_item);
+        if (PERSISTENT && want != 0ull && next_item >= n_items && more_units) {
+            // The pool is empty: on to the next unit.  No lane has left the loop yet (lanes leave only
+            // when there are no more units), and the lanes still busy with items of the old unit hold
+            // everything they need in registers.
+            const uint32_t unit = next_unit(args_in_memory().unit_counter);
+            if (unit < n_units) {
+                n_items = load_unit(A, unit, hash_tab);
+                next_item = 0;
+            } else {
+                more_units = false;
+            }
+        }
         const uint32_t my_item = next_item + lane_prefix(want);
         next_item += (uint32_t)__popcll(want);
-        const bool exiting = need_item && my_item >= n_items; // pool drained: leave after the write-out
-        if (need_item && !exiting) {
+        const bool no_item = need_item && my_item >= n_items; // pool drained
+        // leave after the write-out, unless there is another unit to come: then ask again next time
+        const bool exiting = no_item && !more_units;
+        if (PERSISTENT && no_item) {
+            has_item = false;
+        }
+        if (need_item && !no_item) {
             st.section(ST_ITEM);
             const uint32_t unit_x0 = hash_tab[kUnitWords + 0u], unit_y0 = hash_tab[kUnitWords + 1u];
             const uint32_t tile_w = hash_tab[kUnitWords + 2u];
@@ -528,7 +613,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             samples_left = spp;
             has_item = true;
         }
-        const bool gen = regen && !exiting; // this lane draws a camera sample now
+        const bool gen = regen && !no_item; // this lane draws a camera sample now
 
         // ------------------------------------------------------------------ pixel jitter, :317-320
         float u_coord = 0.0f, v_coord = 0.0f;
@@ -831,6 +916,20 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
 
 namespace {
 
+// Workgroups of `waves_per_block` waves and `lds` bytes that the current device holds at a time
+// (160 KiB of LDS and 32 waves per compute unit).
+uint64_t resident_blocks(size_t lds, uint32_t waves_per_block)
+{
+    int device = 0, cus = 0;
+    if (hipGetDevice(&device) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) {
+        cus = 256;
+    }
+    const uint64_t by_lds = std::max<uint64_t>(1u, (160u * 1024u) / std::max<size_t>(lds, 1u));
+    const uint64_t by_waves = std::max<uint64_t>(1u, 32u / waves_per_block);
+    return static_cast<uint64_t>(cus) * std::min(by_lds, by_waves);
+}
+
 template <int MODE, int BLOCK>
 void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStream_t stream)
 {
@@ -840,7 +939,11 @@ void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStrea
     typedef NoStats StatsPolicy;
 #endif
     const uint32_t waves_per_block = BLOCK / 64;
-    const uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
+    uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
+    if (MODE == kTree) {
+        // persistent waves: no more workgroups than the device holds at a time
+        blocks = std::min<uint64_t>(blocks, resident_blocks(lds, waves_per_block));
+    }
     hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
 }
 
@@ -884,8 +987,13 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         return hipErrorInvalidValue; // several frames need the per-frame sum image
     }
     if (args.tree_nodes != 0) {
-        if (args.tree_geom == nullptr || args.tree_word == nullptr || args.tree_nodes > kTreeMaxNodes) {
+        if (args.tree_geom == nullptr || args.tree_word == nullptr || args.unit_counter == nullptr ||
+            args.tree_nodes > kTreeMaxNodes) {
             return hipErrorInvalidValue;
+        }
+        const hipError_t zeroed = hipMemsetAsync(args.unit_counter, 0, sizeof(uint32_t), stream);
+        if (zeroed != hipSuccess) {
+            return zeroed;
         }
         // a float4 and a word per node; the block size follows the footprint so that a CU's 160 KiB
         // of LDS still hold 16 to 20 waves

@@ -29,6 +29,7 @@ struct TraceArgs {
     uint32_t* stats;              // diagnostic builds only
     const float4* tree_geom;      // hierarchy nodes (rt_tree.hpp), or nullptr
     const uint32_t* tree_word;
+    uint32_t* unit_counter;       // one word the hierarchy kernel hands out its units from (zeroed by launch_trace)
     uint32_t tree_nodes;          // 0 = test every sphere
     uint32_t scene_bounded;       // every sphere finite with |centre| <= 2^20 and |radius| <= 2^20
     uint32_t width;

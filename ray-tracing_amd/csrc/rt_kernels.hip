@@ -142,6 +142,8 @@ struct WaveStats {
 };
 
 // How the sphere list reaches the intersection loop.
+enum Persistence { kOneUnit = 0, kByCounter = 1 };
+
 enum SceneMode {
     kGeomLds = 0, // geometry records in LDS, material records read from memory for the winner
     kFullLds = 1, // whole records in LDS
@@ -377,7 +379,7 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
 // hierarchy uses 256, 512 or 1024 depending on its size.
 // One unit per wave: the launch has as many waves as units.  (Persistent waves that take their next
 // unit from a counter in memory when their pool runs dry were measured 2.8 % slower.)
-template <int MODE, class Stats, int BLOCK>
+template <int MODE, class Stats, int BLOCK, int PERSISTENT>
 __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
     constexpr bool MAT_IN_LDS = MODE == kFullLds;
@@ -399,18 +401,21 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     Stats st;
 
     // ---- this wave's (first) unit ----
-    // With the hierarchy a wave takes one unit after another from a counter in memory (walks are long
-    // and uneven, and a workgroup of sixteen waves holds its LDS until its last wave is through);
-    // otherwise there are as many waves as units.
-    constexpr bool PERSISTENT = MODE == kTree;
+    // With the hierarchy a wave is persistent: it takes one unit after another from a counter in memory
+    // and moves on to the next as soon as its pool is empty, while some of its lanes are still busy with
+    // items of the old one (walks are long and uneven, and a workgroup of sixteen waves holds its LDS
+    // until its last wave is through).  Otherwise there are as many waves as units: for the small scenes
+    // persistent waves were measured slower, with the counter (one atomic per unit: 0.06 -> 0.29 ms for
+    // a 720p frame) as well as with unit numbers a launch-width apart (1080p frame 0.88 -> 1.08 ms).
     const uint32_t n_units = A.n_tiles * A.n_chunks;
     const uint32_t wave_index = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint32_t first_unit = PERSISTENT ? next_unit(A.unit_counter) : wave_index;
+    uint32_t unit = PERSISTENT == kByCounter ? next_unit(A.unit_counter) : wave_index;
+    const uint32_t first_unit = unit;
     const bool spare_wave = first_unit >= n_units;
     const uint32_t full_w = 1u << A.tile_w_log2, full_h = 1u << A.tile_h_log2;
     uint32_t n_items = load_unit(A, min(first_unit, n_units - 1u), hash_tab);
     uint32_t next_item = 0; // wave-uniform pool cursor
-    bool more_units = PERSISTENT; // wave-uniform: the counter has not run past the last unit yet
+    bool more_units = PERSISTENT != kOneUnit; // wave-uniform: the last unit has not been passed yet
     // both end with the workgroup barrier
     if (MODE == kTree) {
         stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, geom, node_word);
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             // The pool is empty: on to the next unit.  No lane has left the loop yet (lanes leave only
             // when there are no more units), and the lanes still busy with items of the old unit hold
             // everything they need in registers.
-            const uint32_t unit = next_unit(args_in_memory().unit_counter);
+            unit = next_unit(args_in_memory().unit_counter);
             if (unit < n_units) {
                 n_items = load_unit(A, unit, hash_tab);
                 next_item = 0;
@@ -930,7 +935,7 @@ uint64_t resident_blocks(size_t lds, uint32_t waves_per_block)
     return static_cast<uint64_t>(cus) * std::min(by_lds, by_waves);
 }
 
-template <int MODE, int BLOCK>
+template <int MODE, int BLOCK, int PERSISTENT>
 void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStream_t stream)
 {
 #ifdef RT_STATS
@@ -940,11 +945,11 @@ void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStrea
 #endif
     const uint32_t waves_per_block = BLOCK / 64;
     uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
-    if (MODE == kTree) {
-        // persistent waves: no more workgroups than the device holds at a time
+    if (PERSISTENT != kOneUnit) {
+        // no more workgroups than the device holds at a time
         blocks = std::min<uint64_t>(blocks, resident_blocks(lds, waves_per_block));
     }
-    hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
+    hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
 }
 
 } // namespace
@@ -966,8 +971,13 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         // (64 frames): 8 x 8 pixels x 16 frames 55.0 Gsamples/s, 8 x 8 x 8 56.6, 4 x 4 x 16 57.2,
         // 2 x 4 x 32 57.8, 2 x 4 x 64 58.2; the number of VALU instructions is the same in all of
         // them, the shorter and more numerous units keep more waves resident.
+        // With the hierarchy units are handed out by a counter, so they can be much smaller: about 32
+        // items.  Rays of neighbouring pixels, and of one pixel in several frames, walk the same nodes
+        // (4096 spheres, 960 x 540, 4 frames: 8 x 8 pixels 31.3 ms, 4 x 8 22.5, 4 x 4 19.9, 2 x 4 19.4,
+        // 2 x 2 20.2, 1 x 1 20.5).
+        const uint32_t target_items = args.tree_nodes != 0 ? 32u : 512u;
         uint32_t log2_pixels = 6;
-        while (log2_pixels > 3u && (args.frames_per_unit << log2_pixels) > 512u) {
+        while (log2_pixels > 3u && (args.frames_per_unit << log2_pixels) > target_items) {
             --log2_pixels;
         }
         args.tile_h_log2 = (log2_pixels + 1u) / 2u;
@@ -987,23 +997,27 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         return hipErrorInvalidValue; // several frames need the per-frame sum image
     }
     if (args.tree_nodes != 0) {
-        if (args.tree_geom == nullptr || args.tree_word == nullptr || args.unit_counter == nullptr ||
-            args.tree_nodes > kTreeMaxNodes) {
+        if (args.unit_counter == nullptr) {
             return hipErrorInvalidValue;
         }
         const hipError_t zeroed = hipMemsetAsync(args.unit_counter, 0, sizeof(uint32_t), stream);
         if (zeroed != hipSuccess) {
             return zeroed;
         }
+    }
+    if (args.tree_nodes != 0) {
+        if (args.tree_geom == nullptr || args.tree_word == nullptr || args.tree_nodes > kTreeMaxNodes) {
+            return hipErrorInvalidValue;
+        }
         // a float4 and a word per node; the block size follows the footprint so that a CU's 160 KiB
         // of LDS still hold 16 to 20 waves
         const size_t nodes_bytes = (size_t)args.tree_nodes * 20u;
         if (nodes_bytes <= 30u * 1024u) {
-            launch_trace_as<kTree, 256>(args, units, nodes_bytes + 4u * kWaveTableWords * 4u, stream);
+            launch_trace_as<kTree, 256, kByCounter>(args, units, nodes_bytes + 4u * kWaveTableWords * 4u, stream);
         } else if (nodes_bytes <= 72u * 1024u) {
-            launch_trace_as<kTree, 512>(args, units, nodes_bytes + 8u * kWaveTableWords * 4u, stream);
+            launch_trace_as<kTree, 512, kByCounter>(args, units, nodes_bytes + 8u * kWaveTableWords * 4u, stream);
         } else {
-            launch_trace_as<kTree, 1024>(args, units, nodes_bytes + 16u * kWaveTableWords * 4u, stream);
+            launch_trace_as<kTree, 1024, kByCounter>(args, units, nodes_bytes + 16u * kWaveTableWords * 4u, stream);
         }
         return hipGetLastError();
     }
@@ -1013,12 +1027,12 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         // One wave per workgroup for scenes whose staging is a handful of records: a finished wave is
         // replaced at once instead of waiting for its three siblings (+1 % on the benchmark).
         if (args.params.frame_sample_depth_count[3] <= 16u) {
-            launch_trace_as<kFullLds, 64>(args, units, lds, stream);
+            launch_trace_as<kFullLds, 64, kOneUnit>(args, units, lds, stream);
         } else {
-            launch_trace_as<kFullLds, 256>(args, units, lds, stream);
+            launch_trace_as<kFullLds, 256, kOneUnit>(args, units, lds, stream);
         }
     } else {
-        launch_trace_as<kGeomLds, 512>(args, units, lds, stream);
+        launch_trace_as<kGeomLds, 512, kOneUnit>(args, units, lds, stream);
     }
     return hipGetLastError();
 }

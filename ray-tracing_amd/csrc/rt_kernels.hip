@@ -245,6 +245,8 @@ struct TreeWalk {
     int best;
     float beyond_limit;  // 2.5 * dot(d,d) * closest^2
     RayDenominator rden;
+    float4 g;            // the node at `at`, fetched ahead
+    uint32_t w;
 };
 
 template <class Stats>
@@ -261,6 +263,8 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
         // the skip tests of the hierarchy are proven for rays in the bounded range only
         if (t.rden.bounded) {
             t.at = 0;
+            t.g = geom[0];
+            t.w = node_word[0];
         } else {
             RT_COLD_PATH();
             for (uint32_t i = 0; i < sphere_count; ++i) {
@@ -280,22 +284,32 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
     do {
         if (t.at < end) {
             st.section(ST_NODE);
-            const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + t.at);
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (t.at >> 2));
+            const float4 g = t.g;
+            const uint32_t w = t.w;
+            // The node after this one is either the next in the array or the one behind this node's
+            // subtree (for a leaf the two coincide); both are fetched now, so that the LDS latency passes
+            // while this node is tested.  Behind the last node both offsets point at the first bytes after
+            // the arrays they index, still inside the workgroup's LDS, and what is read there is not used.
+            const uint32_t seq = t.at + 16u;
+            const uint32_t jump = w & kTreeOffsetMask;
+            const float4 g_seq = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + seq);
+            const uint32_t w_seq = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (seq >> 2));
+            const float4 g_jump = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + jump);
+            const uint32_t w_jump = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (jump >> 2));
             // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
             const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
             const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, t.rden.a, k);
-            uint32_t next = t.at + 16u;
             // A ball (radius R, centre at distance D from the origin) lies wholly beyond the closest
             // hit so far when D > L + R, L = closest * |d|; D^2 - 2 R^2 > 2.5 L^2 implies D > 1.05 (L + R),
             // which no rounding here comes near, so every root inside the ball exceeds `closest`.
-            if (q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit) {
-                next = w & kTreeOffsetMask;
-            } else if ((int32_t)w < 0) {
+            const bool skip = q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit;
+            if (!skip && (int32_t)w < 0) {
                 sphere_closest_any_order(q, t.rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), t.closest, t.best, st);
                 t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
             }
-            t.at = next;
+            t.g = skip ? g_jump : g_seq;
+            t.w = skip ? w_jump : w_seq;
+            t.at = skip ? jump : seq;
         }
     } while ((uint32_t)__popcll(__ballot(t.at < end)) > few);
 }
@@ -464,6 +478,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
 
     TreeWalk walk; // kTree only
     walk.at = 0xFFFFFFFFu;
+    walk.g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    walk.w = 0u;
     walk.closest = 1e20f;
     walk.best = -1;
     walk.beyond_limit = 0.0f;

@@ -369,3 +369,44 @@ def test_rays_outside_the_proven_range_use_the_loop(pkg):
     b = _render(pkg, scene, False, focus=4000.0, aperture=0.0)
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,frames,spp", [(67, 35, 70, 1), (33, 9, 5, 3), (130, 3, 1, 2), (5, 5, 129, 1)])
+def test_hierarchy_unit_boundaries(pkg, w, h, frames, spp):
+    """Ragged tiles, more frames than one chunk holds, single frames: the waves of the hierarchy kernel
+    move from unit to unit while some of their lanes are still busy, and nothing may change."""
+    scene = pkg.synthetic_scene(300)
+    a = _render(pkg, scene, True, w=w, h=h, spp=spp, depth=6, frames=frames)
+    b = _render(pkg, scene, False, w=w, h=h, spp=spp, depth=6, frames=frames)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_hierarchy_frame_by_frame_and_row_shards(pkg):
+    """One launch per frame (as the application renders), and the same frames rendered as row shards,
+    against one batched launch."""
+    scene = pkg.synthetic_scene(300)
+
+    def tracer():
+        t = pkg.RayTracer().create(96, 50, device_id=0)
+        t.set_samples_per_pixel(2)
+        t.set_max_depth(8)
+        t.set_spheres(scene)
+        t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
+        return t
+
+    batch = tracer()
+    batch.render_frames(0, 6)
+    single = tracer()
+    for f in range(6):
+        single.render(f)
+    shards = tracer()
+    shards.render_shard(0, 6, 1, 0, 17, write_output=False)
+    shards.render_shard(0, 6, 1, 17, 50, write_output=False)
+    want = batch.read_accum()
+    assert np.array_equal(single.read_accum().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(shards.read_accum().view(np.uint32), want.view(np.uint32))
+    for t in (batch, single, shards):
+        t.destroy()

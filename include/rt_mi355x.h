@@ -98,7 +98,7 @@ int rt_set_spheres(rt_handle h, const rt_gpu_sphere *spheres, uint32_t n);
 /* Copies out up to cap spheres of the current scene; *n receives the count. */
 int rt_get_spheres(rt_handle h, rt_gpu_sphere *out, uint32_t cap, uint32_t *n);
 
-/* Scenes of 64 spheres or more are traced through a bounding-sphere hierarchy
+/* Scenes of 24 spheres or more are traced through a bounding-sphere hierarchy
  * that rt_set_spheres builds: a ray is only tested against the spheres whose
  * enclosing balls it can reach, each with the arithmetic of hitSphere
  * (shaders/raytrace.comp.glsl:109-133), and the closest-hit rule of :247-259 is

@@ -200,7 +200,7 @@ class RayTracer:
         return np.frombuffer(bytes(buf), dtype=np.float32).reshape(-1, 12).copy()
 
     def set_scene_hierarchy(self, enable):
-        """Scenes of 64 spheres or more are traced through a bounding-sphere hierarchy (same images);
+        """Scenes of 24 spheres or more are traced through a bounding-sphere hierarchy (same images);
         enable=False tests every sphere against every ray like the shader's loop (raytrace.comp.glsl:247-259)."""
         self._check(self._lib.rt_set_scene_hierarchy(self._h, 1 if enable else 0))
 

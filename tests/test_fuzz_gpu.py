@@ -34,7 +34,7 @@ SPECIALS = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 1e-42, 3.0e3
 
 def _case(seed, specials=False):
     rng = np.random.default_rng(seed)
-    count = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 150, 400]))
+    count = int(rng.choice([1, 2, 5, 17, 23, 24, 25, 63, 64, 65, 150, 400]))
     scene = _random_scene(rng, count)
     if specials:
         # out-of-range and non-finite values in geometry and material fields: the shader's arithmetic is

@@ -298,11 +298,11 @@ def test_frame_stride_shards(pkg, oracle):
     odd.destroy()
 
 
-@pytest.mark.parametrize("count,hierarchy", [(2, True), (63, True), (64, True), (64, False), (1024, True), (1024, False),
+@pytest.mark.parametrize("count,hierarchy", [(2, True), (23, True), (24, True), (24, False), (63, True), (64, True), (64, False), (1024, True), (1024, False),
                                              (1500, True), (1500, False), (4096, True), (4096, False)])
 def test_custom_scenes(pkg, oracle, count, hierarchy):
     # with the hierarchy off, 1500 and 4096 spheres exercise the geometry-only LDS layout of the loop
-    # over all spheres (materials fetched from global memory); with it on, scenes of 64 spheres or
+    # over all spheres (materials fetched from global memory); with it on, scenes of 24 spheres or
     # more are walked through the bounding-sphere hierarchy
     scene = pkg.synthetic_scene(count)
     w, h = (48, 32) if count > 1024 else (80, 48)

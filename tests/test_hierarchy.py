@@ -85,9 +85,9 @@ def test_structure(pkg, name):
 def test_scenes_without_hierarchy(pkg):
     t = pkg.RayTracer().create(64, 64, device_id=-1)
     assert len(t.get_scene_hierarchy()[1]) == 0           # the default five spheres
-    t.set_spheres(pkg.synthetic_scene(63))
+    t.set_spheres(pkg.synthetic_scene(23))
     assert len(t.get_scene_hierarchy()[1]) == 0           # below the threshold
-    t.set_spheres(pkg.synthetic_scene(64))
+    t.set_spheres(pkg.synthetic_scene(24))
     assert len(t.get_scene_hierarchy()[1]) > 0
     for field, value in ((0, np.nan), (1, np.inf), (2, 3.0e6), (3, 0.0), (3, 1.0e-25), (3, 2.0e20), (3, np.nan)):
         scene = pkg.synthetic_scene(200)

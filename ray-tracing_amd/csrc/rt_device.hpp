@@ -430,14 +430,14 @@ __device__ __forceinline__ bool sphere_root(float4 geom, f3 o, f3 d, const RayDe
     return sphere_root_from(sphere_quadratic(geom, o, d, rden.a), rden, tmin, tmax, root_out, st);
 }
 
-// The record-filling half of hitSphere, raytrace.comp.glsl:135-143.
-__device__ __forceinline__ void hit_finish(f3 centre, float radius, f3 o, f3 d, float t, f3& p, f3& n, bool& front)
+// The record-filling half of hitSphere, raytrace.comp.glsl:135-143.  rr = refined_rcp(radius), or NaN
+// when the radius is outside the range of the short division sequence.
+__device__ __forceinline__ void hit_finish_with(f3 centre, float radius, float rr, f3 o, f3 d, float t, f3& p, f3& n, bool& front)
 {
     p = o + d * t;
     const f3 pc = p - centre;
     // n = (p - centre) / radius: three divisions by one denominator
-    const float rr = refined_rcp(radius);
-    const bool r_ok = den_in_range(radius);
+    const bool r_ok = rr == rr;
     const float lo = fminf(fminf(fabsf(pc.x), fabsf(pc.y)), fabsf(pc.z));
     const float hi = fmaxf(fmaxf(fabsf(pc.x), fabsf(pc.y)), fabsf(pc.z));
     n = mk(div_core(pc.x, radius, rr), div_core(pc.y, radius, rr), div_core(pc.z, radius, rr));
@@ -449,6 +449,11 @@ __device__ __forceinline__ void hit_finish(f3 centre, float radius, f3 o, f3 d, 
     if (!front) {
         n = -n;
     }
+}
+
+__device__ __forceinline__ void hit_finish(f3 centre, float radius, f3 o, f3 d, float t, f3& p, f3& n, bool& front)
+{
+    hit_finish_with(centre, radius, den_in_range(radius) ? refined_rcp(radius) : __builtin_nanf(""), o, d, t, p, n, front);
 }
 
 // schlick, raytrace.comp.glsl:192-197

@@ -153,7 +153,7 @@ enum SceneMode {
 // Copies the scene into LDS: geometry always, material records when they fit.
 template <bool MAT_IN_LDS>
 __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ spheres, uint32_t count,
-                                            float4* geom, float4* mat0, float4* mat1)
+                                            float4* geom, float4* mat0, float4* mat1, float4* hit_rec)
 {
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
         const float4* src = reinterpret_cast<const float4*>(spheres + i);
@@ -163,6 +163,9 @@ __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ sp
             float4 al = src[1];
             mat0[i] = make_float4(al.x, al.y, al.z, cr.w);
             mat1[i] = src[2];
+            // centre and the reciprocal of the radius as the normal's division uses it (NaN: radius
+            // outside the range of the short division sequence)
+            hit_rec[i] = make_float4(cr.x, cr.y, cr.z, den_in_range(cr.w) ? refined_rcp(cr.w) : __builtin_nanf(""));
         }
     }
     __syncthreads();
@@ -405,11 +408,12 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     float4* geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
+    float4* hit_rec = lds + 3 * sphere_count; // kFullLds only
     uint32_t* node_word = reinterpret_cast<uint32_t*>(lds + lds_records);
     // per-wave tables of the three hash terms of :37-44 for this unit's columns, rows and frames
     // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
     uint32_t* hash_tab = (MODE == kTree ? node_word + lds_records
-                                        : reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 3u : 1u) * sphere_count)) +
+                                        : reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 4u : 1u) * sphere_count)) +
                          (threadIdx.x >> 6) * kWaveTableWords;
 
     Stats st;
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     if (MODE == kTree) {
         stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, geom, node_word);
     } else {
-        stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1);
+        stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1, hit_rec);
     }
     if (spare_wave) {
         return; // the last workgroup may have more waves than units are left
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             st.section(ST_HIT);
             float4 g, m0, m1;
             if (MAT_IN_LDS) {
-                g = geom[best];
+                g = hit_rec[best];
                 m0 = mat0[best];
                 m1 = mat1[best];
             } else {
@@ -541,7 +545,11 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 m0 = make_float4(al.x, al.y, al.z, cr.w);
                 m1 = src[2];
             }
-            hit_finish(mk(g.x, g.y, g.z), m0.w, ro, rd, closest, p, n, front);
+            if (MAT_IN_LDS) {
+                hit_finish_with(mk(g.x, g.y, g.z), m0.w, g.w, ro, rd, closest, p, n, front);
+            } else {
+                hit_finish(mk(g.x, g.y, g.z), m0.w, ro, rd, closest, p, n, front);
+            }
             mat = (uint32_t)(m1.x + 0.5f); // :145
             albedo = mk(m0.x, m0.y, m0.z);
             fuzz = m1.y;
@@ -932,7 +940,7 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
         *mat_in_lds = full;
     }
     // scene records + 80 hash words for each of up to 8 waves
-    return (size_t)sphere_count * (full ? 48u : 16u) + 8u * kWaveTableWords * 4u;
+    return (size_t)sphere_count * (full ? 64u : 16u) + 8u * kWaveTableWords * 4u;
 }
 
 namespace {

@@ -162,7 +162,11 @@ __device__ __forceinline__ void stage_scene(const rt_gpu_sphere* __restrict__ sp
         if (MAT_IN_LDS) {
             float4 al = src[1];
             mat0[i] = make_float4(al.x, al.y, al.z, cr.w);
-            mat1[i] = src[2];
+            // material code as the integer of :145; the slot of the fuzz (read by metal only) holds
+            // 1 / refIdx (:218) for every other material
+            const float4 m = src[2];
+            const uint32_t code = (uint32_t)(m.x + 0.5f);
+            mat1[i] = make_float4(__uint_as_float(code), code == 1u ? m.y : 1.0f / m.z, m.z, m.w);
             // centre and the reciprocal of the radius as the normal's division uses it (NaN: radius
             // outside the range of the short division sequence)
             hit_rec[i] = make_float4(cr.x, cr.y, cr.z, den_in_range(cr.w) ? refined_rcp(cr.w) : __builtin_nanf(""));
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             } else {
                 hit_finish(mk(g.x, g.y, g.z), m0.w, ro, rd, closest, p, n, front);
             }
-            mat = (uint32_t)(m1.x + 0.5f); // :145
+            mat = MAT_IN_LDS ? __float_as_uint(m1.x) : (uint32_t)(m1.x + 0.5f); // :145
             albedo = mk(m0.x, m0.y, m0.z);
             fuzz = m1.y;
             ref_idx = m1.z;
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             // scatterDielectric, :210-234
             st.section(ST_DIEL);
             throughput = throughput * mk(1.0f, 1.0f, 1.0f);
-            float eta_ratio = front ? (1.0f / ref_idx) : ref_idx;
+            float eta_ratio = front ? (MAT_IN_LDS ? fuzz : 1.0f / ref_idx) : ref_idx;
             float cos_theta = glsl_min(dot(-unit, n), 1.0f);
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
             bool do_reflect = eta_ratio * sin_theta > 1.0f;

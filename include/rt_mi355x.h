@@ -92,7 +92,7 @@ int rt_set_max_depth(rt_handle h, uint32_t depth);
 
 /* Replaces the sphere list that RayTracer::buildScene/uploadScene
  * (src/rt/RayTracer.cpp:105-138, :529-548) hard-code.  The reference has no
- * public counterpart; this is what larger scenes enter through.  n >= 1.
+ * public counterpart; this is what larger scenes enter through.  1 <= n <= 2^20.
  * Raises the reset flag. */
 int rt_set_spheres(rt_handle h, const rt_gpu_sphere *spheres, uint32_t n);
 /* Copies out up to cap spheres of the current scene; *n receives the count. */
@@ -112,8 +112,16 @@ int rt_set_scene_hierarchy(rt_handle h, int enable);
  * leaf, 1.125 R^2 for an inner node), word one 32-bit value per node (bit 31
  * leaf, bits 17..30 sphere index of a leaf, bits 0..16 byte offset = 16 * index
  * of the node to continue with when the node's test fails).  *n_nodes receives
- * the node count, 0 when the scene has no hierarchy.  Either array may be NULL. */
+ * the node count, 0 when the scene has no hierarchy.  Either array may be NULL.
+ * A hierarchy of more than 8191 nodes does not fit these bit fields: asking for
+ * its words fails (geom and *n_nodes are still delivered); use the call below. */
 int rt_get_scene_hierarchy(rt_handle h, float *geom, uint32_t *word, uint32_t cap, uint32_t *n_nodes);
+/* The same hierarchy with whole words, for trees of any size (scenes of up to
+ * 2^20 spheres): link receives per node the index of the node to continue with
+ * when the node's test fails, sphere the sphere index of a leaf or 0xFFFFFFFF for
+ * an inner node.  No counterpart in the reference.  Any array may be NULL. */
+int rt_get_scene_hierarchy_links(rt_handle h, float *geom, uint32_t *link, uint32_t *sphere, uint32_t cap,
+                                 uint32_t *n_nodes);
 
 /* RayTracer::makeCameraParams + updateParams, src/rt/RayTracer.cpp:140-177,
  * :550-557: the 160-byte block a dispatch for frame_index would receive. */

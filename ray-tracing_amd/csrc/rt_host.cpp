@@ -50,6 +50,8 @@ struct rt_tracer {
     float4* d_tree_geom = nullptr;
     uint32_t* d_tree_word = nullptr;
     uint32_t* d_unit_counter = nullptr;
+    float4* d_loop_geom = nullptr;
+    uint32_t d_loop_geom_capacity = 0;
     uint32_t d_tree_capacity = 0;
 
     bool reset_accum = true;          // mResetAccum
@@ -269,9 +271,9 @@ void index_scene(rt_tracer* h)
 int upload_scene(rt_tracer* h, hipStream_t stream)
 {
     const uint32_t n = static_cast<uint32_t>(h->spheres.size());
+    // the previous scene may still be read by a kernel in flight
+    RT_HIP_TRY(h, hipDeviceSynchronize());
     if (n > h->d_sphere_capacity) {
-        // the previous buffer may still be read by a kernel in flight
-        RT_HIP_TRY(h, hipDeviceSynchronize());
         if (h->d_spheres) {
             (void)hipFree(h->d_spheres);
             h->d_spheres = nullptr;
@@ -280,25 +282,59 @@ int upload_scene(rt_tracer* h, hipStream_t stream)
         RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_spheres), n * sizeof(rt_gpu_sphere)));
         h->d_sphere_capacity = n;
     }
+    // The node arrays hold one entry more than the tree has nodes: the walk fetches the node behind
+    // the one it is testing, also behind the last.  Words: one per node (packed) or two (wide).
     const uint32_t nodes = h->tree.node_count();
-    if (nodes > h->d_tree_capacity) {
-        RT_HIP_TRY(h, hipDeviceSynchronize());
-        if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); h->d_tree_geom = nullptr; }
-        if (h->d_tree_word) { (void)hipFree(h->d_tree_word); h->d_tree_word = nullptr; }
-        h->d_tree_capacity = 0;
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_geom), nodes * sizeof(float4)));
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_word), nodes * sizeof(uint32_t)));
-        h->d_tree_capacity = nodes;
-    }
-    if (nodes != 0 && h->d_unit_counter == nullptr) {
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_unit_counter), 256));
-    }
-    // pageable-memory copies: each returns once the source has been staged, ordered on the stream
-    RT_HIP_TRY(h, hipMemcpyAsync(h->d_spheres, h->spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice, stream));
     if (nodes != 0) {
-        RT_HIP_TRY(h, hipMemcpyAsync(h->d_tree_geom, h->tree.geom.data(), nodes * sizeof(float4), hipMemcpyHostToDevice, stream));
-        RT_HIP_TRY(h, hipMemcpyAsync(h->d_tree_word, h->tree.word.data(), nodes * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        std::vector<float> geom(h->tree.geom);
+        geom.resize((static_cast<size_t>(nodes) + 1u) * 4u, 0.0f);
+        std::vector<uint32_t> words;
+        if (h->tree.packed()) {
+            words = h->tree.word;
+            words.push_back(0u);
+        } else {
+            words.resize((static_cast<size_t>(nodes) + 1u) * 2u, 0u);
+            for (uint32_t i = 0; i < nodes; ++i) {
+                words[2u * i] = h->tree.link[i] * 16u;
+                words[2u * i + 1u] = h->tree.sphere[i] == rt::kTreeNoSphere ? 0u : rt::kTreeLeafFlag | h->tree.sphere[i];
+            }
+        }
+        if (nodes > h->d_tree_capacity) {
+            RT_HIP_TRY(h, hipDeviceSynchronize());
+            if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); h->d_tree_geom = nullptr; }
+            if (h->d_tree_word) { (void)hipFree(h->d_tree_word); h->d_tree_word = nullptr; }
+            h->d_tree_capacity = 0;
+            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_geom), (static_cast<size_t>(nodes) + 1u) * sizeof(float4)));
+            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_word), (static_cast<size_t>(nodes) + 1u) * 2u * sizeof(uint32_t)));
+            h->d_tree_capacity = nodes;
+        }
+        if (h->d_unit_counter == nullptr) {
+            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_unit_counter), 256));
+        }
+        RT_HIP_TRY(h, hipMemcpy(h->d_tree_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+        RT_HIP_TRY(h, hipMemcpy(h->d_tree_word, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    if (n > rt::kMaxSpheresGeomLds) {
+        // (centre, radius^2) records for the loop over all spheres in global memory
+        std::vector<float> geom(static_cast<size_t>(n) * 4u);
+        for (uint32_t i = 0; i < n; ++i) {
+            const float* cr = h->spheres[i].center_radius;
+            geom[4u * i + 0u] = cr[0];
+            geom[4u * i + 1u] = cr[1];
+            geom[4u * i + 2u] = cr[2];
+            geom[4u * i + 3u] = cr[3] * cr[3];
+        }
+        if (n > h->d_loop_geom_capacity) {
+            RT_HIP_TRY(h, hipDeviceSynchronize());
+            if (h->d_loop_geom) { (void)hipFree(h->d_loop_geom); h->d_loop_geom = nullptr; }
+            h->d_loop_geom_capacity = 0;
+            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_loop_geom), static_cast<size_t>(n) * sizeof(float4)));
+            h->d_loop_geom_capacity = n;
+        }
+        RT_HIP_TRY(h, hipMemcpy(h->d_loop_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // pageable-memory copy: returns once the source has been staged, ordered on the stream
+    RT_HIP_TRY(h, hipMemcpyAsync(h->d_spheres, h->spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice, stream));
     RT_HIP_TRY(h, hipStreamSynchronize(stream));
     return RT_OK;
 }
@@ -443,6 +479,8 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.tree_word = tree ? h->d_tree_word : nullptr;
         args.unit_counter = tree ? h->d_unit_counter : nullptr;
         args.tree_nodes = tree ? h->tree.node_count() : 0u;
+        args.tree_packed = tree && h->tree.packed() ? 1u : 0u;
+        args.loop_geom = h->d_loop_geom;
         args.scene_bounded = h->scene_bounded ? 1u : 0u;
         args.width = h->width;
         args.height = h->height;
@@ -583,6 +621,7 @@ int rt_destroy(rt_handle h)
         if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); }
         if (h->d_tree_word) { (void)hipFree(h->d_tree_word); }
         if (h->d_unit_counter) { (void)hipFree(h->d_unit_counter); }
+        if (h->d_loop_geom) { (void)hipFree(h->d_loop_geom); }
         for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
             if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }
@@ -669,7 +708,7 @@ int rt_set_spheres(rt_handle h, const rt_gpu_sphere* spheres, uint32_t n)
         return fail_arg(h, "sphere list is empty");
     }
     if (n > rt::kMaxSpheres) {
-        return fail_arg(h, "more than 4096 spheres");
+        return fail_arg(h, "more than 1048576 spheres");
     }
     h->spheres.assign(spheres, spheres + n);
     index_scene(h);
@@ -720,7 +759,32 @@ int rt_get_scene_hierarchy(rt_handle h, float* geom, uint32_t* word, uint32_t ca
         std::memcpy(geom, h->tree.geom.data(), sizeof(float) * 4 * take);
     }
     if (word != nullptr && take != 0) {
+        if (!h->tree.packed()) {
+            return fail_arg(h, "the hierarchy is too large for packed node words; use rt_get_scene_hierarchy_links");
+        }
         std::memcpy(word, h->tree.word.data(), sizeof(uint32_t) * take);
+    }
+    return RT_OK;
+}
+
+int rt_get_scene_hierarchy_links(rt_handle h, float* geom, uint32_t* link, uint32_t* sphere, uint32_t cap, uint32_t* n_nodes)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    const uint32_t count = h->tree.node_count();
+    if (n_nodes != nullptr) {
+        *n_nodes = count;
+    }
+    const uint32_t take = std::min(cap, count);
+    if (geom != nullptr && take != 0) {
+        std::memcpy(geom, h->tree.geom.data(), sizeof(float) * 4 * take);
+    }
+    if (link != nullptr && take != 0) {
+        std::memcpy(link, h->tree.link.data(), sizeof(uint32_t) * take);
+    }
+    if (sphere != nullptr && take != 0) {
+        std::memcpy(sphere, h->tree.sphere.data(), sizeof(uint32_t) * take);
     }
     return RT_OK;
 }

@@ -147,7 +147,9 @@ enum Persistence { kOneUnit = 0, kByCounter = 1 };
 enum SceneMode {
     kGeomLds = 0, // geometry records in LDS, material records read from memory for the winner
     kFullLds = 1, // whole records in LDS
-    kTree = 2     // hierarchy nodes in LDS, sphere records read from memory for the winner
+    kTree = 2,    // hierarchy nodes in LDS, sphere records read from memory for the winner
+    kTreeGlobal = 3, // hierarchy too large for LDS (or for the packed node word): walked in global memory
+    kGeomGlobal = 4  // no hierarchy and too many spheres for LDS: geometry records read from global memory
 };
 
 // Copies the scene into LDS: geometry always, material records when they fit.
@@ -254,9 +256,24 @@ struct TreeWalk {
     RayDenominator rden;
     float4 g;            // the node at `at`, fetched ahead
     uint32_t w;
+    uint32_t link;       // byte offset of the node to continue at when this node's test fails
 };
 
-template <class Stats>
+// One node's words: packed (one word, rt_tree.hpp) or wide (continuation offset, then leaf flag | sphere index).
+template <bool WIDE>
+__device__ __forceinline__ void load_node_words(const uint32_t* node_word, uint32_t at, uint32_t& w, uint32_t& link)
+{
+    if (WIDE) {
+        const uint2 ww = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(node_word) + (at >> 1));
+        link = ww.x;
+        w = ww.y;
+    } else {
+        w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (at >> 2));
+        link = w & kTreeOffsetMask;
+    }
+}
+
+template <bool WIDE, class Stats>
 __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom, const uint32_t* node_word, uint32_t sphere_count,
                                           bool live, f3 ro, f3 rd, TreeWalk& t, Stats& st)
 {
@@ -271,7 +288,7 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
         if (t.rden.bounded) {
             t.at = 0;
             t.g = geom[0];
-            t.w = node_word[0];
+            load_node_words<WIDE>(node_word, 0u, t.w, t.link);
         } else {
             RT_COLD_PATH();
             for (uint32_t i = 0; i < sphere_count; ++i) {
@@ -298,11 +315,12 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
             // while this node is tested.  Behind the last node both offsets point at the first bytes after
             // the arrays they index, still inside the workgroup's LDS, and what is read there is not used.
             const uint32_t seq = t.at + 16u;
-            const uint32_t jump = w & kTreeOffsetMask;
+            const uint32_t jump = t.link;
             const float4 g_seq = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + seq);
-            const uint32_t w_seq = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (seq >> 2));
             const float4 g_jump = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + jump);
-            const uint32_t w_jump = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (jump >> 2));
+            uint32_t w_seq, link_seq, w_jump, link_jump;
+            load_node_words<WIDE>(node_word, seq, w_seq, link_seq);
+            load_node_words<WIDE>(node_word, jump, w_jump, link_jump);
             // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
             const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
             const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, t.rden.a, k);
@@ -311,11 +329,13 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
             // which no rounding here comes near, so every root inside the ball exceeds `closest`.
             const bool skip = q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit;
             if (!skip && (int32_t)w < 0) {
-                sphere_closest_any_order(q, t.rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), t.closest, t.best, st);
+                sphere_closest_any_order(q, t.rden, kTMin, (int)((w & ~kTreeLeafFlag) >> (WIDE ? 0u : kTreeIndexShift)), t.closest,
+                                         t.best, st);
                 t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
             }
             t.g = skip ? g_jump : g_seq;
             t.w = skip ? w_jump : w_seq;
+            t.link = skip ? link_jump : link_seq;
             t.at = skip ? jump : seq;
         }
     } while ((uint32_t)__popcll(__ballot(t.at < end)) > few);
@@ -408,16 +428,20 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t sphere_count = A.params.frame_sample_depth_count[3];
     // records ahead of the hash tables: the scene (1 or 3 float4 per sphere) or the hierarchy
     // (a float4 and a word per node)
-    const uint32_t lds_records = MODE == kTree ? A.tree_nodes : sphere_count;
-    float4* geom = lds;
+    constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal;
+    constexpr bool IN_GLOBAL = MODE == kTreeGlobal || MODE == kGeomGlobal; // nothing but the hash tables in LDS
+    const uint32_t lds_records = IN_GLOBAL ? 0u : (MODE == kTree ? A.tree_nodes : sphere_count);
+    float4* lds_geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
     float4* hit_rec = lds + 3 * sphere_count; // kFullLds only
-    uint32_t* node_word = reinterpret_cast<uint32_t*>(lds + lds_records);
+    uint32_t* lds_word = reinterpret_cast<uint32_t*>(lds + lds_records);
+    const float4* geom = MODE == kTreeGlobal ? A.tree_geom : (MODE == kGeomGlobal ? A.loop_geom : lds_geom);
+    const uint32_t* node_word = MODE == kTreeGlobal ? A.tree_word : lds_word;
     // per-wave tables of the three hash terms of :37-44 for this unit's columns, rows and frames
     // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
-    uint32_t* hash_tab = (MODE == kTree ? node_word + lds_records
-                                        : reinterpret_cast<uint32_t*>(lds + (MAT_IN_LDS ? 4u : 1u) * sphere_count)) +
+    uint32_t* hash_tab = (MODE == kTree ? lds_word + lds_records
+                                        : reinterpret_cast<uint32_t*>(lds + (IN_GLOBAL ? 0u : (MAT_IN_LDS ? 4u : 1u)) * sphere_count)) +
                          (threadIdx.x >> 6) * kWaveTableWords;
 
     Stats st;
@@ -440,9 +464,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     bool more_units = PERSISTENT != kOneUnit; // wave-uniform: the last unit has not been passed yet
     // both end with the workgroup barrier
     if (MODE == kTree) {
-        stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, geom, node_word);
-    } else {
-        stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, geom, mat0, mat1, hit_rec);
+        stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, lds_geom, lds_word);
+    } else if (!IN_GLOBAL) {
+        stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, lds_geom, mat0, mat1, hit_rec);
     }
     if (spare_wave) {
         return; // the last workgroup may have more waves than units are left
@@ -484,10 +508,11 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     f3 ro = origin, rd = origin;
     f3 throughput = mk(1.0f, 1.0f, 1.0f);
 
-    TreeWalk walk; // kTree only
+    TreeWalk walk; // hierarchy only
     walk.at = 0xFFFFFFFFu;
     walk.g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     walk.w = 0u;
+    walk.link = 0u;
     walk.closest = 1e20f;
     walk.best = -1;
     walk.beyond_limit = 0.0f;
@@ -516,8 +541,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         rden.a_ok = true;
         rden.bounded = false;
         bool traced = live; // the lane's segment has been searched to its end in this iteration
-        if (MODE == kTree) {
-            tree_walk(A, geom, node_word, sphere_count, live, ro, rd, walk, st);
+        if (TREE) {
+            tree_walk<MODE == kTreeGlobal>(A, geom, node_word, sphere_count, live, ro, rd, walk, st);
             traced = live && walk.at >= A.tree_nodes * 16u;
             closest = walk.closest;
             best = traced ? walk.best : -1;
@@ -545,7 +570,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 const float4* src = reinterpret_cast<const float4*>(A.spheres + best);
                 const float4 cr = src[0];
                 const float4 al = src[1];
-                g = MODE == kTree ? cr : geom[best]; // only the centre is used
+                g = cr; // only the centre is used
                 m0 = make_float4(al.x, al.y, al.z, cr.w);
                 m1 = src[2];
             }
@@ -578,7 +603,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         bool regen = path_done;
         // (not with the hierarchy: there a waiting lane idles through a walk of a hundred nodes, which
         // costs more than the blocks it would share are worth -- measured 65.3 against 62.4 ms on one box)
-        if (kRegenQuorum != 0u && MODE != kTree) {
+        if (kRegenQuorum != 0u && !TREE) {
             const unsigned long long done_mask = __ballot(path_done);
             const unsigned long long in_loop = __ballot(true);
             regen = path_done && ((uint32_t)__popcll(done_mask) >= kRegenQuorum || done_mask == in_loop);
@@ -1034,8 +1059,12 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         }
     }
     if (args.tree_nodes != 0) {
-        if (args.tree_geom == nullptr || args.tree_word == nullptr || args.tree_nodes > kTreeMaxNodes) {
+        if (args.tree_geom == nullptr || args.tree_word == nullptr || (args.tree_packed != 0 && args.tree_nodes > kTreeMaxNodes)) {
             return hipErrorInvalidValue;
+        }
+        if (args.tree_packed == 0) {
+            launch_trace_as<kTreeGlobal, 256, kByCounter>(args, units, 4u * kWaveTableWords * 4u, stream);
+            return hipGetLastError();
         }
         // a float4 and a word per node; the block size follows the footprint so that a CU's 160 KiB
         // of LDS still hold 16 to 20 waves
@@ -1047,6 +1076,13 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         } else {
             launch_trace_as<kTree, 1024, kByCounter>(args, units, nodes_bytes + 16u * kWaveTableWords * 4u, stream);
         }
+        return hipGetLastError();
+    }
+    if (args.params.frame_sample_depth_count[3] > kMaxSpheresGeomLds) {
+        if (args.loop_geom == nullptr) {
+            return hipErrorInvalidValue;
+        }
+        launch_trace_as<kGeomGlobal, 256, kOneUnit>(args, units, 4u * kWaveTableWords * 4u, stream);
         return hipGetLastError();
     }
     bool full = false;

@@ -12,8 +12,11 @@ namespace rt {
 
 // Largest sphere count whose full 48-byte records are staged in LDS.
 constexpr uint32_t kMaxSpheresFullLds = 1024;
-// Largest sphere count the tracer accepts (16-byte geometry records: 64 KiB of LDS).
-constexpr uint32_t kMaxSpheres = 4096;
+// Largest sphere count whose 16-byte geometry records are staged in LDS (64 KiB) when every ray
+// tests every sphere; beyond it that loop reads them from global memory.
+constexpr uint32_t kMaxSpheresGeomLds = 4096;
+// Largest sphere count the tracer accepts.
+constexpr uint32_t kMaxSpheres = 1u << 20;
 
 // Kernel arguments of one trace launch.  `params` is the reference's uniform
 // block (raytrace.comp.glsl:19-31) passed by value, so it lands in scalar
@@ -28,9 +31,12 @@ struct TraceArgs {
     float4* partial;              // [n_frames][height*width] per-frame sums; required when n_frames > 1
     uint32_t* stats;              // diagnostic builds only
     const float4* tree_geom;      // hierarchy nodes (rt_tree.hpp), or nullptr
-    const uint32_t* tree_word;
+    const uint32_t* tree_word;    // one packed word per node, or two words per node (tree_packed == 0)
+    const float4* loop_geom;      // (centre, radius^2) per sphere in global memory, for scenes beyond kMaxSpheresGeomLds without a hierarchy
     uint32_t* unit_counter;       // one word the hierarchy kernel hands out its units from (zeroed by launch_trace)
     uint32_t tree_nodes;          // 0 = test every sphere
+    uint32_t tree_packed;         // the hierarchy fits LDS and the packed word; otherwise it is walked in global memory,
+                                  // and both node arrays hold one more (unused) entry than tree_nodes
     uint32_t scene_bounded;       // every sphere finite with |centre| <= 2^20 and |radius| <= 2^20
     uint32_t width;
     uint32_t height;

@@ -46,13 +46,13 @@ struct Item {
 struct Builder {
     std::vector<Item> items;
     SphereTree* out;
-    bool overflow = false;
 
-    uint32_t emit(const float g[4], uint32_t word)
+    uint32_t emit(const float g[4], uint32_t link, uint32_t sphere)
     {
         const uint32_t at = out->node_count();
         out->geom.insert(out->geom.end(), g, g + 4);
-        out->word.push_back(word);
+        out->link.push_back(link);
+        out->sphere.push_back(sphere);
         return at;
     }
 
@@ -60,8 +60,7 @@ struct Builder {
     {
         const float* cr = spheres[it.index].center_radius;
         const float g[4] = { cr[0], cr[1], cr[2], cr[3] * cr[3] }; // the kernel's staging computes the same product
-        const uint32_t at = out->node_count();
-        emit(g, kTreeLeafFlag | (it.index << kTreeIndexShift) | ((at + 1u) * 16u));
+        emit(g, out->node_count() + 1u, it.index);
     }
 
     // Ball around the midpoint of the bounding box of items[lo, hi); centre rounded to float first.
@@ -130,19 +129,15 @@ struct Builder {
         }
         float g[4];
         bounding_ball(lo, hi, g);
-        const uint32_t at = emit(g, 0u);
+        const uint32_t at = emit(g, 0u, kTreeNoSphere);
         emit_children(lo, hi, spheres);
-        out->word[at] = out->node_count() * 16u;
+        out->link[at] = out->node_count();
     }
 
     // Children of a node (or the top level): up to four parts, each a leaf or a node of its own;
     // four or fewer spheres become leaves directly.
     void emit_children(uint32_t lo, uint32_t hi, const rt_gpu_sphere* spheres)
     {
-        if (out->node_count() + (hi - lo) > kTreeMaxNodes) {
-            overflow = true;
-            return;
-        }
         if (hi - lo <= 4) {
             for (uint32_t i = lo; i < hi; ++i) {
                 emit_leaf(items[i], spheres);
@@ -173,9 +168,8 @@ struct Builder {
 
 bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree& out)
 {
-    out.geom.clear();
-    out.word.clear();
-    if (spheres == nullptr || count < kTreeMinSpheres || count > (kTreeLeafFlag >> kTreeIndexShift) - 1u) {
+    out.clear();
+    if (spheres == nullptr || count < kTreeMinSpheres || count > kTreeMaxSpheres) {
         return false;
     }
     Builder b;
@@ -197,10 +191,13 @@ bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree&
         b.items[i].index = i;
     }
     b.emit_children(0, count, spheres);
-    if (b.overflow || out.node_count() > kTreeMaxNodes) {
-        out.geom.clear();
-        out.word.clear();
-        return false;
+    const uint32_t nodes = out.node_count();
+    if (nodes <= kTreeMaxNodes && count <= (kTreeLeafFlag >> kTreeIndexShift)) {
+        out.word.resize(nodes);
+        for (uint32_t i = 0; i < nodes; ++i) {
+            const uint32_t leaf = out.sphere[i] == kTreeNoSphere ? 0u : kTreeLeafFlag | (out.sphere[i] << kTreeIndexShift);
+            out.word[i] = leaf | (out.link[i] * 16u);
+        }
     }
     return true;
 }

@@ -18,6 +18,10 @@
 //             the whole subtree
 // A ray visits node i; if the node's test fails it continues at the offset in the word, otherwise
 // at i + 1 (the first child, or simply the next node after a leaf).
+//
+// Trees too large for those bit fields (more than kTreeMaxNodes nodes) keep two words per node
+// instead: the byte offset of the node to continue at, and 1<<31 | sphere index (0 for an internal
+// node); such trees are walked in global memory.
 #pragma once
 
 #include <stdint.h>
@@ -43,16 +47,31 @@ constexpr uint32_t kTreeIndexShift = 17;
 // Most nodes a tree may have: offsets are 17 bits of bytes / 16.
 constexpr uint32_t kTreeMaxNodes = 8191;
 
+// Largest scene a hierarchy is built for (byte offsets of nodes stay below 2^32 with room to spare).
+constexpr uint32_t kTreeMaxSpheres = 1u << 20;
+constexpr uint32_t kTreeNoSphere = 0xFFFFFFFFu;
+
 struct SphereTree {
-    std::vector<float> geom;     // 4 floats per node
-    std::vector<uint32_t> word;  // 1 per node
-    uint32_t node_count() const { return static_cast<uint32_t>(word.size()); }
-    bool empty() const { return word.empty(); }
+    std::vector<float> geom;       // 4 floats per node
+    std::vector<uint32_t> link;    // per node: index of the node to continue at when the node's test fails
+    std::vector<uint32_t> sphere;  // per node: sphere index of a leaf, kTreeNoSphere for an internal node
+    std::vector<uint32_t> word;    // per node: the packed word; empty when the tree does not fit the bit fields
+    uint32_t node_count() const { return static_cast<uint32_t>(link.size()); }
+    bool empty() const { return link.empty(); }
+    bool packed() const { return !word.empty(); }
+    void clear()
+    {
+        geom.clear();
+        link.clear();
+        sphere.clear();
+        word.clear();
+    }
 };
 
 // Builds the hierarchy.  Returns false (and leaves `out` empty) when the scene does not qualify:
-// fewer than kTreeMinSpheres spheres, or any centre/radius outside the ranges the error bounds
-// were derived for (non-finite values, |centre| > 2^20, radius^2 outside [2^-40, 2^40]).
+// fewer than kTreeMinSpheres or more than kTreeMaxSpheres spheres, or any centre/radius outside the
+// ranges the error bounds were derived for (non-finite values, |centre| > 2^20, radius^2 outside
+// [2^-40, 2^40]).
 bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree& out);
 
 } // namespace rt

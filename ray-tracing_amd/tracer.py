@@ -61,6 +61,8 @@ ABI = {
     "rt_get_spheres": (ctypes.c_int, [_H, ctypes.POINTER(GPUSphere), _U32, ctypes.POINTER(_U32)]),
     "rt_set_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_int]),
     "rt_get_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.POINTER(_U32)]),
+    "rt_get_scene_hierarchy_links": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _U32,
+                                                    ctypes.POINTER(_U32)]),
     "rt_get_params": (ctypes.c_int, [_H, _U32, ctypes.POINTER(GPUParams)]),
     "rt_reset_accumulation": (ctypes.c_int, [_H]),
     "rt_render": (ctypes.c_int, [_H, _U32, _STREAM]),
@@ -214,6 +216,20 @@ class RayTracer:
             self._check(self._lib.rt_get_scene_hierarchy(self._h, geom.ctypes.data, word.ctypes.data, n.value,
                                                          ctypes.byref(n)))
         return geom, word
+
+    def get_scene_hierarchy_links(self):
+        """(geom (n, 4) float32, link (n,) uint32, sphere (n,) uint32) of the current scene's hierarchy, for
+        trees of any size: link = node to continue with when a node's test fails, sphere = sphere index of
+        a leaf or 0xFFFFFFFF."""
+        n = _U32()
+        self._check(self._lib.rt_get_scene_hierarchy_links(self._h, None, None, None, 0, ctypes.byref(n)))
+        geom = np.zeros((n.value, 4), dtype=np.float32)
+        link = np.zeros((n.value,), dtype=np.uint32)
+        sphere = np.zeros((n.value,), dtype=np.uint32)
+        if n.value:
+            self._check(self._lib.rt_get_scene_hierarchy_links(self._h, geom.ctypes.data, link.ctypes.data,
+                                                               sphere.ctypes.data, n.value, ctypes.byref(n)))
+        return geom, link, sphere
 
     def get_params(self, frame_index=0):
         p = GPUParams()

@@ -107,10 +107,10 @@ def test_errors_are_status_codes_with_messages(pkg):
     except RuntimeError as e:
         assert "empty" in str(e)
     try:
-        t.set_spheres(np.zeros((4097, 12), dtype=np.float32))
+        t.set_spheres(np.zeros(((1 << 20) + 1, 12), dtype=np.float32))
         assert False
     except RuntimeError as e:
-        assert "4096" in str(e)
+        assert "1048576" in str(e)
     t.set_spheres(pkg.synthetic_scene(64))
     assert t.get_params(0).frame_sample_depth_count[3] == 64
     t.destroy()

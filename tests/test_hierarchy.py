@@ -410,3 +410,79 @@ def test_hierarchy_frame_by_frame_and_row_shards(pkg):
     assert np.array_equal(shards.read_accum().view(np.uint32), want.view(np.uint32))
     for t in (batch, single, shards):
         t.destroy()
+
+
+def _check_links(scene, geom, link, sphere):
+    n = len(link)
+    leaf = sphere != 0xFFFFFFFF
+    assert leaf.sum() == len(scene)
+    assert sorted(sphere[leaf].tolist()) == list(range(len(scene)))
+    s = scene[sphere[leaf]]
+    assert np.array_equal(geom[leaf, :3], s[:, :3])
+    assert np.array_equal(geom[leaf, 3], s[:, 3] * s[:, 3])
+    at = np.nonzero(leaf)[0]
+    assert np.array_equal(link[leaf], (at + 1).astype(np.uint32))
+    inner = np.nonzero(~leaf)[0]
+    assert np.all(link[inner] > inner + 1) and np.all(link[inner] <= n)
+    # every node's ball (R^2 = w / 1.125) holds the spheres of its subtree; checked through the chain
+    # child ball + distance <= parent ball would be too strict (balls are built from the spheres), so
+    # sample inner nodes instead
+    rng = np.random.default_rng(1)
+    for i in rng.choice(inner, size=min(len(inner), 300), replace=False):
+        sub = np.arange(i + 1, link[i])
+        sl = sub[leaf[sub]]
+        centre = geom[i, :3].astype(np.float64)
+        radius = np.sqrt(float(geom[i, 3]) / 1.125)
+        c = geom[sl, :3].astype(np.float64)
+        r = np.sqrt(geom[sl, 3].astype(np.float64))
+        assert np.all(np.sqrt(((c - centre) ** 2).sum(1)) + r <= radius * (1.0 + 1e-6))
+        assert np.all(link[sub[~leaf[sub]]] <= link[i])
+
+
+def test_links_agree_with_packed_words_and_cover_large_scenes(pkg):
+    small = pkg.synthetic_scene(500)
+    t = _host(pkg, small)
+    geom, word = t.get_scene_hierarchy()
+    geom2, link, sphere = t.get_scene_hierarchy_links()
+    assert np.array_equal(geom, geom2)
+    assert np.array_equal(word & 0x1FFFF, link * 16)
+    leaf = (word & LEAF) != 0
+    assert np.array_equal(leaf, sphere != 0xFFFFFFFF)
+    assert np.array_equal(((word[leaf] & 0x7FFFFFFF) >> 17), sphere[leaf])
+    _check_links(small, geom2, link, sphere)
+    big = pkg.synthetic_scene(9000)
+    t.set_spheres(big)
+    geom, link, sphere = t.get_scene_hierarchy_links()
+    assert len(link) > 8191                      # beyond the packed format
+    _check_links(big, geom, link, sphere)
+    with pytest.raises(RuntimeError, match="too large for packed"):
+        t.get_scene_hierarchy()
+    t.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count", [6000, 20000])
+def test_scenes_beyond_lds(pkg, oracle, count):
+    """More spheres than LDS holds: the hierarchy is walked in global memory, the loop over all spheres
+    reads its geometry records from global memory; both against the oracle."""
+    from test_gpu_parity import oracle_frames, same
+    scene = pkg.synthetic_scene(count)
+    results = []
+    for hierarchy in (True, False):
+        t = pkg.RayTracer().create(40, 24, device_id=0)
+        t.set_samples_per_pixel(2)
+        t.set_max_depth(6)
+        t.set_spheres(scene)
+        t.set_scene_hierarchy(hierarchy)
+        t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
+        t.enable_rng_capture(True)
+        t.render_frames(0, 3)
+        results.append((t.read_accum(), t.read_rng_state(), t.read_output()))
+        if hierarchy:
+            ref = oracle_frames(oracle, t, scene, range(3), want_rng=True)
+        t.destroy()
+    for x, y in zip(*results):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    assert same(results[0][1], ref["rng"])
+    assert same(results[0][0], ref["accum"])
+    assert same(results[0][2], ref["output"])

@@ -34,12 +34,15 @@ def load_flops_per_sample():
 
 def load_measured_traffic():
     """HBM bytes per trace launch from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE); None if not recorded."""
+    (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE); None if not recorded.
+    Profiles of this command live in profiles/r<round><letter>/; directories with a suffix
+    (r1i_c5m ...) hold other workloads."""
+    import re
     best = None
     base = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(base)):
         path = os.path.join(base, name, "pmc_summary.json")
-        if os.path.isfile(path):
+        if re.fullmatch(r"r\d+[a-z]*", name) and os.path.isfile(path):
             d = json.load(open(path)).get("_derived", {})
             if "hbm_read_bytes_per_launch" in d:
                 best = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]

@@ -5,10 +5,10 @@
 //
 // Work decomposition.  The unit of independent work is an ITEM = one (pixel, frame) pair: its
 // `spp` samples share one random stream (:310-331) whose draw count per sample is data dependent,
-// so they stay on one lane, in order.  A wave owns a UNIT = one 8x8 pixel tile x a chunk of up to
-// `frames_per_unit` frames, i.e. a pool of up to 64 x frames_per_unit items.  Lanes pull items from
-// the pool with a ballot/prefix count (no atomics, no LDS): a lane that finishes its item takes the
-// next one, so all 64 lanes stay busy until the pool drains, whatever the path lengths were.
+// so they stay on one lane, in order.  A wave owns a UNIT = a small pixel tile (2x4 to 8x8, chosen
+// per launch) x a chunk of up to `frames_per_unit` frames.  Lanes pull items from that pool with a
+// ballot/prefix count (no atomics, no LDS): a lane that finishes its item takes the next one, so
+// all 64 lanes stay busy until the pool drains, whatever the path lengths were.
 //
 // The loop body is one RAY SEGMENT per lane: the bounce loop (:242-293) and the sample loop
 // (:315-331) are flattened, and a lane whose path ended generates its next camera ray in the same
@@ -27,7 +27,9 @@
 //
 // Scenes of kTreeMinSpheres spheres or more are traced through a bounding-sphere hierarchy
 // (rt_tree.hpp): each lane walks the depth-first node array on its own, one node per trip, and a
-// leaf goes through the same arithmetic as in the plain loop.
+// leaf goes through the same arithmetic as in the plain loop.  A lane's walk may stretch over several
+// iterations of the trace loop (tree_walk), and the waves of that kernel take their units from a
+// counter in memory.  Trees too large for LDS are walked in global memory.
 //
 // Compile with -ffp-contract=off (see rt_device.hpp).
 #include "rt_device.hpp"
@@ -415,18 +417,19 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
     return u.n_items;
 }
 
-// BLOCK = threads per workgroup: 256 for scenes whose whole records fit in LDS, 512 for the
-// geometry-only layout (64 KiB of LDS per workgroup: two workgroups, 16 waves, per CU); the
-// hierarchy uses 256, 512 or 1024 depending on its size.
-// One unit per wave: the launch has as many waves as units.  (Persistent waves that take their next
-// unit from a counter in memory when their pool runs dry were measured 2.8 % slower.)
+// BLOCK = threads per workgroup: 64 for scenes of up to 16 spheres, 256 for larger ones whose whole
+// records fit in LDS, 512 for the geometry-only layout (64 KiB of LDS per workgroup: two workgroups,
+// 16 waves, per CU); the hierarchy uses 256, 512 or 1024 depending on its size.
+// PERSISTENT = kOneUnit: the launch has as many waves as units (for the benchmark, waves that take
+// their next unit from a counter when their pool runs dry were measured 2.8 % slower);
+// kByCounter: the hierarchy kernels, see below.
 template <int MODE, class Stats, int BLOCK, int PERSISTENT>
 __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
     constexpr bool MAT_IN_LDS = MODE == kFullLds;
     extern __shared__ float4 lds[];
     const uint32_t sphere_count = A.params.frame_sample_depth_count[3];
-    // records ahead of the hash tables: the scene (1 or 3 float4 per sphere) or the hierarchy
+    // records ahead of the hash tables: the scene (1 or 4 float4 per sphere) or the hierarchy
     // (a float4 and a word per node)
     constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal;
     constexpr bool IN_GLOBAL = MODE == kTreeGlobal || MODE == kGeomGlobal; // nothing but the hash tables in LDS

@@ -71,12 +71,13 @@ constexpr uint32_t kWalkQuorum = RT_WALK_QUORUM;
 // number of active lanes.  The shipped library instantiates the kernel with NoStats only.
 enum Section {
     ST_ITER, ST_ITEM, ST_GEN, ST_DISK_IT, ST_NORM2, ST_ROOT, ST_FAR_ROOT, ST_HIT, ST_RIS, ST_RIS_IT,
-    ST_SKY, ST_LAMBERT, ST_CHECKER, ST_METAL, ST_DIEL, ST_SCHLICK, ST_NODE, ST_COUNT
+    ST_SKY, ST_LAMBERT, ST_CHECKER, ST_METAL, ST_DIEL, ST_SCHLICK, ST_NODE, ST_ALL_PRIMARY, ST_SPHERE_TEST, ST_COUNT
 };
 
 enum Phase { PH_NORM2, PH_INTERSECT, PH_HIT, PH_ITEM, PH_SAMPLER, PH_NORM1, PH_SHADE, PH_TAIL, PH_COUNT };
 
 struct NoStats {
+    [[maybe_unused]] static constexpr bool kEnabled = false;
     __device__ __forceinline__ void section(int) {}
     __device__ __forceinline__ void phase_start() {}
     __device__ __forceinline__ void phase_end(int) {}
@@ -84,6 +85,7 @@ struct NoStats {
 };
 
 struct WaveStats {
+    [[maybe_unused]] static constexpr bool kEnabled = true;
     uint32_t exec[ST_COUNT];
     uint32_t lanes[ST_COUNT];
     unsigned long long phase_cycles[PH_COUNT]; // shader-clock cycles between phase marks (wave-uniform)
@@ -200,12 +202,22 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
 // `best` come back as the loop of :247-259 leaves them (1e20 and -1 without a hit).
 template <int MODE, class Stats>
 __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* geom, const uint32_t* node_word, uint32_t sphere_count,
-                                            f3 ro, f3 rd, RayDenominator& rden, float& closest, int& best, Stats& st)
+                                            uint32_t sphere_mask, f3 ro, f3 rd, RayDenominator& rden, float& closest, int& best,
+                                            Stats& st)
 {
     constexpr bool MAT_IN_LDS = MODE == kFullLds;
     closest = 1e20f;
     best = -1;
     rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
+    if (sphere_mask != 0xFFFFFFFFu) {
+        // small scenes: the spheres of the mask, in index order
+        for (uint32_t m = sphere_mask; m != 0u; m &= m - 1u) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m);
+            st.section(ST_SPHERE_TEST);
+            sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
+        }
+        return;
+    }
     uint32_t i = 0;
     if (!MAT_IN_LDS) {
         // Large scenes: four records per trip, fetched together so that one LDS wait covers
@@ -497,6 +509,47 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     // component both steps are skipped; the two draws of randomInUnitDisk are still consumed.
     const bool pinhole = lens_radius == 0.0f && origin.x != 0.0f && origin.y != 0.0f && origin.z != 0.0f;
 
+    // Small scenes: which spheres a camera ray of this unit's tile can hit at all.  The rays of the tile
+    // leave the camera position (or a point of the lens, at most 1.5 lens radii from it) in directions
+    // dc + delta, |delta| <= rho, dc the direction through the middle of the tile.  A ray at angle phi to
+    // w = centre - origin passes the centre at distance |w| sin(phi), and sin is 1-Lipschitz, so every
+    // ray of the tile stays at least q_c - |w| theta away, q_c the distance of the middle ray and
+    // theta <= 1.6 rho / |dc| the half angle of the bundle.  hitSphere's discriminant can only come out
+    // non-negative when that distance is below r + 0.0014 |w| (ten roundings of relative 2^-24 in
+    // :112-117 for rays of unit length and a bounded scene); with 0.002 |w| and another 0.1 % of margin
+    // the rounding of this estimate itself (relative 1e-6) does not matter.  A NaN anywhere keeps the sphere.
+    // (rho < |dc| / 4 is required of both tests.)
+    constexpr bool CULL = MAT_IN_LDS && BLOCK == 64;
+    const uint32_t full_mask = CULL ? (1u << sphere_count) - 1u : 0xFFFFFFFFu; // at most 16 spheres
+    uint32_t camera_mask = full_mask;
+    if (CULL && A.scene_bounded != 0u && (fabsf(origin.x) + fabsf(origin.y)) + fabsf(origin.z) < 0x1p30f) {
+        const uint32_t lane = threadIdx.x & 63u;
+        bool keep = lane < sphere_count;
+        if (lane < sphere_count) {
+            const float tile_x0 = (float)hash_tab[kUnitWords + 0u], tile_y0 = (float)hash_tab[kUnitWords + 1u];
+            const float half_w = 0.5f * (float)hash_tab[kUnitWords + 2u], half_h = 0.5f * (float)hash_tab[kUnitWords + 3u];
+            const float uc = (tile_x0 + half_w) * inv_w;
+            const float vc = ((A.params.resolution[1] - tile_y0) - half_h) * inv_h; // :320 flips y
+            const f3 dc = lower_left + horizontal * uc + vertical * vc - origin;
+            const float lens = 1.5f * fabsf(lens_radius);
+            const float rho = ((half_w * inv_w) * sqrtf(dot(horizontal, horizontal)) + (half_h * inv_h) * sqrtf(dot(vertical, vertical)) +
+                               lens) * 1.001f;
+            const float4 g = geom[lane];
+            const f3 w = mk(g.x, g.y, g.z) - origin;
+            const f3 cr = mk(w.y * dc.z - w.z * dc.y, w.z * dc.x - w.x * dc.z, w.x * dc.y - w.y * dc.x);
+            const float len_dc = sqrtf(dot(dc, dc)), len_w = sqrtf(dot(w, w));
+            const float q_c = sqrtf(dot(cr, cr)) / len_dc;
+            const float reach = (sqrtf(g.w) + lens) * 1.001f;
+            const bool misses = rho < 0.25f * len_dc && q_c - len_w * (1.6f * rho / len_dc) - 0.002f * len_w > reach;
+            // Or the sphere lies behind every ray: origin outside it and dot(oc, d) > 0 by a margin, so
+            // that :121-131 find both roots negative (the lines of such rays do cross the ground sphere).
+            const bool behind = rho < 0.25f * len_dc && len_w - lens > 1.01f * sqrtf(g.w) &&
+                                dot(w, dc) + len_w * rho + (0.002f * len_w + lens) * len_dc < 0.0f;
+            keep = !(misses || behind);
+        }
+        camera_mask = (uint32_t)__ballot(keep);
+    }
+
     // ---- per-lane state ----
     bool has_item = false;
     bool live = false;         // the lane carries a ray that has to be traced in this iteration
@@ -544,6 +597,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         rden.a_ok = true;
         rden.bounded = false;
         bool traced = live; // the lane's segment has been searched to its end in this iteration
+        if (Stats::kEnabled && live && __ballot(live && depth != 0u) == 0ull) {
+            st.section(ST_ALL_PRIMARY); // every ray of the wave in this iteration is a camera ray
+        }
         if (TREE) {
             tree_walk<MODE == kTreeGlobal>(A, geom, node_word, sphere_count, live, ro, rd, walk, st);
             traced = live && walk.at >= A.tree_nodes * 16u;
@@ -551,7 +607,14 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             best = traced ? walk.best : -1;
             rden = walk.rden;
         } else if (live) {
-            closest_hit<MODE>(A, geom, node_word, sphere_count, ro, rd, rden, closest, best, st);
+            // when every ray of the wave is a camera ray of this unit, only the spheres its tile can see
+            uint32_t sphere_mask = 0xFFFFFFFFu;
+            if (CULL) {
+                // (the loop over a mask is 1.4 % slower than the counted loop when it has to visit every
+                // sphere anyway, so it is only used with a reduced mask)
+                sphere_mask = __ballot(live && depth != 0u) == 0ull && camera_mask != full_mask ? camera_mask : 0xFFFFFFFFu;
+            }
+            closest_hit<MODE>(A, geom, node_word, sphere_count, sphere_mask, ro, rd, rden, closest, best, st);
         }
         st.phase_end(PH_INTERSECT);
         const bool hit = best >= 0; // only lanes whose segment has been searched can hit

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SECTIONS = ["iter", "item", "gen", "disk_it", "norm2", "root", "far_root", "hit", "ris", "ris_it",
-            "sky", "lambert", "checker", "metal", "diel", "schlick", "node"]
+            "sky", "lambert", "checker", "metal", "diel", "schlick", "node", "all_primary", "sphere_test"]
 
 
 def main():

@@ -50,8 +50,6 @@ struct rt_tracer {
     float4* d_tree_geom = nullptr;
     uint32_t* d_tree_word = nullptr;
     uint32_t* d_unit_counter = nullptr;
-    uint32_t* d_tile_mask = nullptr;
-    uint32_t tile_mask_capacity = 0;
     float4* d_loop_geom = nullptr;
     uint32_t d_loop_geom_capacity = 0;
     uint32_t d_tree_capacity = 0;
@@ -238,7 +236,6 @@ void free_images(rt_tracer* h)
     if (h->accum) { (void)hipFree(h->accum); h->accum = nullptr; }
     if (h->output) { (void)hipFree(h->output); h->output = nullptr; }
     if (h->rng_state) { (void)hipFree(h->rng_state); h->rng_state = nullptr; }
-    if (h->d_tile_mask) { (void)hipFree(h->d_tile_mask); h->d_tile_mask = nullptr; h->tile_mask_capacity = 0; }
     if (h->partial) { (void)hipFree(h->partial); h->partial = nullptr; h->partial_bytes = 0; }
 }
 
@@ -249,15 +246,6 @@ int allocate_images(rt_tracer* h)
     const size_t pixels = static_cast<size_t>(h->width) * h->height;
     RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->accum), pixels * sizeof(float4)));
     RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->output), pixels * sizeof(uint32_t)));
-    // one word per pixel tile of a launch (tiles of 8 pixels or more: the default unit geometries)
-    const size_t tiles = (static_cast<size_t>(h->width) + 1u) / 2u * ((static_cast<size_t>(h->height) + 3u) / 4u) + 64u;
-    if (tiles <= 0x7FFFFFFFull) {
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tile_mask), tiles * sizeof(uint32_t)));
-        h->tile_mask_capacity = static_cast<uint32_t>(tiles);
-    }
-    if (h->d_unit_counter == nullptr) {
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_unit_counter), 256));
-    }
     RT_HIP_TRY(h, hipMemset(h->output, 0, pixels * sizeof(uint32_t)));
     if (h->rng_capture) {
         RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->rng_state), pixels * sizeof(uint32_t)));
@@ -489,9 +477,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         const bool tree = h->use_tree && !h->tree.empty();
         args.tree_geom = tree ? h->d_tree_geom : nullptr;
         args.tree_word = tree ? h->d_tree_word : nullptr;
-        args.unit_counter = h->d_unit_counter;
-        args.tile_mask = h->d_tile_mask;
-        args.tile_mask_capacity = h->tile_mask_capacity;
+        args.unit_counter = tree ? h->d_unit_counter : nullptr;
         args.tree_nodes = tree ? h->tree.node_count() : 0u;
         args.tree_packed = tree && h->tree.packed() ? 1u : 0u;
         args.loop_geom = h->d_loop_geom;
@@ -635,7 +621,6 @@ int rt_destroy(rt_handle h)
         if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); }
         if (h->d_tree_word) { (void)hipFree(h->d_tree_word); }
         if (h->d_unit_counter) { (void)hipFree(h->d_unit_counter); }
-        if (h->d_tile_mask) { (void)hipFree(h->d_tile_mask); }
         if (h->d_loop_geom) { (void)hipFree(h->d_loop_geom); }
         for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }

@@ -37,7 +37,6 @@
 #include "rt_tree.hpp"
 
 #include <algorithm>
-#include <cmath>
 #include <cstdlib>
 
 namespace rt {
@@ -426,7 +425,6 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
         hash_tab[kUnitWords + 3u] = u.tile_h;
         hash_tab[kUnitWords + 4u] = u.tile_pixels;
         hash_tab[kUnitWords + 5u] = u.rel_begin;
-        hash_tab[kUnitWords + 6u] = A.tile_mask != nullptr ? A.tile_mask[tile] : 0xFFFFFFFFu;
     }
     return u.n_items;
 }
@@ -511,17 +509,46 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     // component both steps are skipped; the two draws of randomInUnitDisk are still consumed.
     const bool pinhole = lens_radius == 0.0f && origin.x != 0.0f && origin.y != 0.0f && origin.z != 0.0f;
 
-    // Small scenes: in iterations whose rays are all camera rays only the spheres are tested that a camera
-    // ray of the tile can hit at all (rt_tile_mask_kernel works that out per tile ahead of the launch;
-    // load_unit leaves the current unit's mask in LDS).
+    // Small scenes: which spheres a camera ray of this unit's tile can hit at all.  The rays of the tile
+    // leave the camera position (or a point of the lens, at most 1.5 lens radii from it) in directions
+    // dc + delta, |delta| <= rho, dc the direction through the middle of the tile.  A ray at angle phi to
+    // w = centre - origin passes the centre at distance |w| sin(phi), and sin is 1-Lipschitz, so every
+    // ray of the tile stays at least q_c - |w| theta away, q_c the distance of the middle ray and
+    // theta <= 1.6 rho / |dc| the half angle of the bundle.  hitSphere's discriminant can only come out
+    // non-negative when that distance is below r + 0.0014 |w| (ten roundings of relative 2^-24 in
+    // :112-117 for rays of unit length and a bounded scene); with 0.002 |w| and another 0.1 % of margin
+    // the rounding of this estimate itself (relative 1e-6) does not matter.  A NaN anywhere keeps the sphere.
+    // (rho < |dc| / 4 is required of both tests.)
     constexpr bool CULL = MAT_IN_LDS && BLOCK == 64;
     const uint32_t full_mask = CULL ? (1u << sphere_count) - 1u : 0xFFFFFFFFu; // at most 16 spheres
-    // A persistent wave moves on to its next unit while some lanes still work on items of earlier ones:
-    // until those are finished (`earlier_items` = the lanes that hold them) the mask is the union of the
-    // masks of all units since, afterwards that of the current unit alone.
-    uint32_t unit_mask = CULL ? __builtin_amdgcn_readfirstlane(hash_tab[kUnitWords + 6u]) & full_mask : full_mask;
-    uint32_t camera_mask = unit_mask;
-    unsigned long long earlier_items = 0ull;
+    uint32_t camera_mask = full_mask;
+    if (CULL && A.scene_bounded != 0u && (fabsf(origin.x) + fabsf(origin.y)) + fabsf(origin.z) < 0x1p30f) {
+        const uint32_t lane = threadIdx.x & 63u;
+        bool keep = lane < sphere_count;
+        if (lane < sphere_count) {
+            const float tile_x0 = (float)hash_tab[kUnitWords + 0u], tile_y0 = (float)hash_tab[kUnitWords + 1u];
+            const float half_w = 0.5f * (float)hash_tab[kUnitWords + 2u], half_h = 0.5f * (float)hash_tab[kUnitWords + 3u];
+            const float uc = (tile_x0 + half_w) * inv_w;
+            const float vc = ((A.params.resolution[1] - tile_y0) - half_h) * inv_h; // :320 flips y
+            const f3 dc = lower_left + horizontal * uc + vertical * vc - origin;
+            const float lens = 1.5f * fabsf(lens_radius);
+            const float rho = ((half_w * inv_w) * sqrtf(dot(horizontal, horizontal)) + (half_h * inv_h) * sqrtf(dot(vertical, vertical)) +
+                               lens) * 1.001f;
+            const float4 g = geom[lane];
+            const f3 w = mk(g.x, g.y, g.z) - origin;
+            const f3 cr = mk(w.y * dc.z - w.z * dc.y, w.z * dc.x - w.x * dc.z, w.x * dc.y - w.y * dc.x);
+            const float len_dc = sqrtf(dot(dc, dc)), len_w = sqrtf(dot(w, w));
+            const float q_c = sqrtf(dot(cr, cr)) / len_dc;
+            const float reach = (sqrtf(g.w) + lens) * 1.001f;
+            const bool misses = rho < 0.25f * len_dc && q_c - len_w * (1.6f * rho / len_dc) - 0.002f * len_w > reach;
+            // Or the sphere lies behind every ray: origin outside it and dot(oc, d) > 0 by a margin, so
+            // that :121-131 find both roots negative (the lines of such rays do cross the ground sphere).
+            const bool behind = rho < 0.25f * len_dc && len_w - lens > 1.01f * sqrtf(g.w) &&
+                                dot(w, dc) + len_w * rho + (0.002f * len_w + lens) * len_dc < 0.0f;
+            keep = !(misses || behind);
+        }
+        camera_mask = (uint32_t)__ballot(keep);
+    }
 
     // ---- per-lane state ----
     bool has_item = false;
@@ -667,20 +694,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             if (unit < n_units) {
                 n_items = load_unit(A, unit, hash_tab);
                 next_item = 0;
-                if (CULL) {
-                    unit_mask = __builtin_amdgcn_readfirstlane(hash_tab[kUnitWords + 6u]) & full_mask;
-                    camera_mask |= unit_mask;
-                    earlier_items = __ballot(has_item);
-                }
             } else {
                 more_units = false;
-            }
-        }
-        if (CULL && PERSISTENT != kOneUnit) {
-            // whoever asks for an item gets one of the current unit, or none
-            earlier_items &= ~want;
-            if (earlier_items == 0ull) {
-                camera_mask = unit_mask;
             }
         }
         const uint32_t my_item = next_item + lane_prefix(want);
@@ -898,63 +913,6 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     st.flush(A.stats);
 }
 
-// Small scenes: which spheres a camera ray of a pixel tile can hit at all, one thread per tile of the
-// launch (bit i = sphere i has to be tested).  The rays of the tile leave the camera position (or a
-// point of the lens, at most 1.5 lens radii from it) in directions dc + delta, |delta| <= rho, dc the
-// direction through the middle of the tile.  A ray at angle phi to w = centre - origin passes the
-// centre at distance |w| sin(phi), and sin is 1-Lipschitz, so every ray of the tile stays at least
-// q_c - |w| theta away, q_c the distance of the middle ray and theta <= 1.6 rho / |dc| the half angle
-// of the bundle.  hitSphere's discriminant can only come out non-negative when that distance is below
-// r + 0.0014 |w| (ten roundings of relative 2^-24 in :112-117 for rays of unit length and a bounded
-// scene); with 0.002 |w| and another 0.1 % of margin the rounding of this estimate itself (relative
-// 1e-6) does not matter.  A NaN anywhere keeps the sphere.  (rho < |dc| / 4 is required of both tests.)
-__global__ __launch_bounds__(kBlockThreads) void rt_tile_mask_kernel(TraceArgs A)
-{
-    const uint32_t tile = blockIdx.x * kBlockThreads + threadIdx.x;
-    if (tile >= A.n_tiles) {
-        return;
-    }
-    const uint32_t sphere_count = A.params.frame_sample_depth_count[3];
-    const uint32_t tile_y = tile / A.tiles_x;
-    const uint32_t tile_x = tile - tile_y * A.tiles_x;
-    const uint32_t x0 = tile_x << A.tile_w_log2;
-    const uint32_t y0 = A.row_begin + (tile_y << A.tile_h_log2);
-    const uint32_t tile_w = min(1u << A.tile_w_log2, A.width - x0);
-    const uint32_t tile_h = min(1u << A.tile_h_log2, A.row_end - y0);
-    const f3 origin = mk(A.params.origin_lens[0], A.params.origin_lens[1], A.params.origin_lens[2]);
-    const f3 lower_left = mk(A.params.lower_left[0], A.params.lower_left[1], A.params.lower_left[2]);
-    const f3 horizontal = mk(A.params.horizontal[0], A.params.horizontal[1], A.params.horizontal[2]);
-    const f3 vertical = mk(A.params.vertical[0], A.params.vertical[1], A.params.vertical[2]);
-    const float inv_w = A.params.inv_resolution[0], inv_h = A.params.inv_resolution[1];
-    const float half_w = 0.5f * (float)tile_w, half_h = 0.5f * (float)tile_h;
-    const float uc = ((float)x0 + half_w) * inv_w;
-    const float vc = ((A.params.resolution[1] - (float)y0) - half_h) * inv_h; // :320 flips y
-    const f3 dc = lower_left + horizontal * uc + vertical * vc - origin;
-    const float lens = 1.5f * fabsf(A.params.origin_lens[3]);
-    const float rho = ((half_w * inv_w) * sqrtf(dot(horizontal, horizontal)) + (half_h * inv_h) * sqrtf(dot(vertical, vertical)) +
-                       lens) * 1.001f;
-    const float len_dc = sqrtf(dot(dc, dc));
-    uint32_t mask = 0u;
-    for (uint32_t i = 0; i < sphere_count; ++i) {
-        const float4 s = *reinterpret_cast<const float4*>(A.spheres + i);
-        const float r2 = s.w * s.w;
-        const f3 w = mk(s.x, s.y, s.z) - origin;
-        const f3 cr = mk(w.y * dc.z - w.z * dc.y, w.z * dc.x - w.x * dc.z, w.x * dc.y - w.y * dc.x);
-        const float len_w = sqrtf(dot(w, w));
-        const float q_c = sqrtf(dot(cr, cr)) / len_dc;
-        const float reach = (sqrtf(r2) + lens) * 1.001f;
-        const bool misses = rho < 0.25f * len_dc && q_c - len_w * (1.6f * rho / len_dc) - 0.002f * len_w > reach;
-        // Or the sphere lies behind every ray: origin outside it and dot(oc, d) > 0 by a margin, so
-        // that :121-131 find both roots negative (the lines of such rays do cross the ground sphere).
-        const bool behind = rho < 0.25f * len_dc && len_w - lens > 1.01f * sqrtf(r2) &&
-                            dot(w, dc) + len_w * rho + (0.002f * len_w + lens) * len_dc < 0.0f;
-        if (!(misses || behind)) {
-            mask |= 1u << i;
-        }
-    }
-    A.tile_mask[tile] = mask;
-}
-
 // Adds the per-frame sums of a multi-frame launch to the accumulator in frame order (:333-335 of
 // consecutive dispatches) and, if asked, runs the display tail of the last frame (:337-342).
 __global__ __launch_bounds__(kBlockThreads) void rt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ partial,
@@ -1082,17 +1040,6 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
 
 namespace {
 
-// Whether a launch of the small-scene kernel uses persistent waves: RT_PERSISTENT=0/1 decides (experiments).
-bool small_scene_persistence(const TraceArgs& args)
-{
-    static const int forced = [] {
-        const char* e = std::getenv("RT_PERSISTENT");
-        return e == nullptr ? -1 : (std::atoi(e) != 0 ? 1 : 0);
-    }();
-    (void)args;
-    return forced == 1;
-}
-
 // Workgroups of `waves_per_block` waves and `lds` bytes that the current device holds at a time
 // (160 KiB of LDS and 32 waves per compute unit).
 uint64_t resident_blocks(size_t lds, uint32_t waves_per_block)
@@ -1168,22 +1115,7 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     if (args.n_frames > 1 && args.partial == nullptr) {
         return hipErrorInvalidValue; // several frames need the per-frame sum image
     }
-    // Scenes of up to 16 spheres (without a hierarchy): per-tile masks of the spheres camera rays can hit.
-    // The estimate is proven for bounded scenes and camera positions only.
-    const uint32_t sphere_count = args.params.frame_sample_depth_count[3];
-    const float* cam = args.params.origin_lens;
-    const bool tile_masks = args.tree_nodes == 0 && sphere_count <= 16u && args.tile_mask != nullptr &&
-                            args.n_tiles <= args.tile_mask_capacity && args.scene_bounded != 0u &&
-                            (std::fabs(cam[0]) + std::fabs(cam[1])) + std::fabs(cam[2]) < 0x1p30f;
-    if (tile_masks) {
-        hipLaunchKernelGGL(rt_tile_mask_kernel, dim3((args.n_tiles + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0,
-                           stream, args);
-    } else {
-        args.tile_mask = nullptr;
-    }
-    // persistent waves (the hierarchy; small scenes on request) take their units from a counter
-    const bool small_persistent = args.tree_nodes == 0 && sphere_count <= 16u && small_scene_persistence(args);
-    if (args.tree_nodes != 0 || small_persistent) {
+    if (args.tree_nodes != 0) {
         if (args.unit_counter == nullptr) {
             return hipErrorInvalidValue;
         }
@@ -1225,11 +1157,7 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         // One wave per workgroup for scenes whose staging is a handful of records: a finished wave is
         // replaced at once instead of waiting for its three siblings (+1 % on the benchmark).
         if (args.params.frame_sample_depth_count[3] <= 16u) {
-            if (small_persistent) {
-                launch_trace_as<kFullLds, 64, kByCounter>(args, units, lds, stream);
-            } else {
-                launch_trace_as<kFullLds, 64, kOneUnit>(args, units, lds, stream);
-            }
+            launch_trace_as<kFullLds, 64, kOneUnit>(args, units, lds, stream);
         } else {
             launch_trace_as<kFullLds, 256, kOneUnit>(args, units, lds, stream);
         }

@@ -33,8 +33,6 @@ struct TraceArgs {
     const float4* tree_geom;      // hierarchy nodes (rt_tree.hpp), or nullptr
     const uint32_t* tree_word;    // one packed word per node, or two words per node (tree_packed == 0)
     const float4* loop_geom;      // (centre, radius^2) per sphere in global memory, for scenes beyond kMaxSpheresGeomLds without a hierarchy
-    uint32_t* tile_mask;          // small scenes: one word per pixel tile (written by launch_trace), or nullptr
-    uint32_t tile_mask_capacity;  // words in tile_mask
     uint32_t* unit_counter;       // one word the hierarchy kernel hands out its units from (zeroed by launch_trace)
     uint32_t tree_nodes;          // 0 = test every sphere
     uint32_t tree_packed;         // the hierarchy fits LDS and the packed word; otherwise it is walked in global memory,

@@ -34,9 +34,10 @@ namespace rt {
 
 // Scenes smaller than this are traced by the plain loop.  Measured on MI355X with the synthetic grid
 // scene (960 x 540, 8 spp, depth 16, 4 frames; loop / hierarchy in ms): 8 spheres 1.20 / 1.35,
-// 12: 1.58 / 1.45, 16: 1.77 / 1.52, 24: 2.22 / 1.94, 32: 2.89 / 1.98, 64: 4.59 / 2.57.  A scene whose
-// spheres all overlap gains nothing from the walk and pays about twice the loop, hence not the
-// break-even point itself.
+// 12: 1.58 / 1.45, 16: 1.77 / 1.52, 24: 2.22 / 1.94, 32: 2.89 / 1.98, 64: 4.59 / 2.57.  Scenes whose
+// spheres all overlap, are nested or stand in a row seen end-on gain nothing from the walk: measured
+// between 15 % faster and 50 % slower than the loop at 24 to 200 spheres, hence not the break-even
+// point itself.
 #ifndef RT_TREE_MIN_SPHERES
 #define RT_TREE_MIN_SPHERES 24
 #endif

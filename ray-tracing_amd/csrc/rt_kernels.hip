@@ -37,6 +37,7 @@
 #include "rt_tree.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace rt {
@@ -1067,6 +1068,11 @@ void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStrea
     if (PERSISTENT != kOneUnit) {
         // no more workgroups than the device holds at a time
         blocks = std::min<uint64_t>(blocks, resident_blocks(lds, waves_per_block));
+    }
+    if (std::getenv("RT_DEBUG_OCCUPANCY") != nullptr) {
+        int per_cu = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT>, BLOCK, lds);
+        fprintf(stderr, "occupancy: %d workgroups of %d threads per CU, lds %zu, blocks %llu\n", per_cu, BLOCK, lds, (unsigned long long)blocks);
     }
     hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
 }

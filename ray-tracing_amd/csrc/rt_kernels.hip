@@ -154,7 +154,9 @@ enum SceneMode {
     kFullLds = 1, // whole records in LDS
     kTree = 2,    // hierarchy nodes in LDS, sphere records read from memory for the winner
     kTreeGlobal = 3, // hierarchy too large for LDS (or for the packed node word): walked in global memory
-    kGeomGlobal = 4  // no hierarchy and too many spheres for LDS: geometry records read from global memory
+    kGeomGlobal = 4, // no hierarchy and too many spheres for LDS: geometry records read from global memory
+    kFullLds5 = 5    // kFullLds for exactly five spheres (the reference's own scene, src/rt/RayTracer.cpp:105-138):
+                     // the sphere loop is unrolled and every LDS offset is a constant
 };
 
 // Copies the scene into LDS: geometry always, material records when they fit.
@@ -206,7 +208,7 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
                                             uint32_t sphere_mask, f3 ro, f3 rd, RayDenominator& rden, float& closest, int& best,
                                             Stats& st)
 {
-    constexpr bool MAT_IN_LDS = MODE == kFullLds;
+    constexpr bool MAT_IN_LDS = MODE == kFullLds || MODE == kFullLds5;
     closest = 1e20f;
     best = -1;
     rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
@@ -215,6 +217,13 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
         for (uint32_t m = sphere_mask; m != 0u; m &= m - 1u) {
             const uint32_t i = (uint32_t)__builtin_ctz(m);
             st.section(ST_SPHERE_TEST);
+            sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
+        }
+        return;
+    }
+    if (MODE == kFullLds5) {
+#pragma unroll
+        for (uint32_t i = 0; i < 5u; ++i) {
             sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
         }
         return;
@@ -439,9 +448,9 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
 template <int MODE, class Stats, int BLOCK, int PERSISTENT>
 __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
-    constexpr bool MAT_IN_LDS = MODE == kFullLds;
+    constexpr bool MAT_IN_LDS = MODE == kFullLds || MODE == kFullLds5;
     extern __shared__ float4 lds[];
-    const uint32_t sphere_count = A.params.frame_sample_depth_count[3];
+    const uint32_t sphere_count = MODE == kFullLds5 ? 5u : A.params.frame_sample_depth_count[3];
     // records ahead of the hash tables: the scene (1 or 4 float4 per sphere) or the hierarchy
     // (a float4 and a word per node)
     constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal;
@@ -1163,7 +1172,11 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         // One wave per workgroup for scenes whose staging is a handful of records: a finished wave is
         // replaced at once instead of waiting for its three siblings (+1 % on the benchmark).
         if (args.params.frame_sample_depth_count[3] <= 16u) {
-            launch_trace_as<kFullLds, 64, kOneUnit>(args, units, lds, stream);
+            if (args.params.frame_sample_depth_count[3] == 5u) {
+                launch_trace_as<kFullLds5, 64, kOneUnit>(args, units, lds, stream);
+            } else {
+                launch_trace_as<kFullLds, 64, kOneUnit>(args, units, lds, stream);
+            }
         } else {
             launch_trace_as<kFullLds, 256, kOneUnit>(args, units, lds, stream);
         }

@@ -212,18 +212,22 @@ __device__ __forceinline__ void closest_hit(const TraceArgs& A, const float4* ge
     closest = 1e20f;
     best = -1;
     rden = ray_denominator(ro, rd, A.scene_bounded != 0u);
+    if (MODE == kFullLds5) {
+        // unrolled, a scalar branch per sphere; the mask is 31 unless every ray is a camera ray
+#pragma unroll
+        for (uint32_t i = 0; i < 5u; ++i) {
+            if ((sphere_mask & (1u << i)) != 0u) {
+                st.section(ST_SPHERE_TEST);
+                sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
+            }
+        }
+        return;
+    }
     if (sphere_mask != 0xFFFFFFFFu) {
         // small scenes: the spheres of the mask, in index order
         for (uint32_t m = sphere_mask; m != 0u; m &= m - 1u) {
             const uint32_t i = (uint32_t)__builtin_ctz(m);
             st.section(ST_SPHERE_TEST);
-            sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
-        }
-        return;
-    }
-    if (MODE == kFullLds5) {
-#pragma unroll
-        for (uint32_t i = 0; i < 5u; ++i) {
             sphere_closest(sphere_quadratic(geom[i], ro, rd, rden.a), rden, kTMin, (int)i, closest, best, st);
         }
         return;
@@ -623,6 +627,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 // (the loop over a mask is 1.4 % slower than the counted loop when it has to visit every
                 // sphere anyway, so it is only used with a reduced mask)
                 sphere_mask = __ballot(live && depth != 0u) == 0ull && camera_mask != full_mask ? camera_mask : 0xFFFFFFFFu;
+                if (MODE == kFullLds5) {
+                    sphere_mask &= 31u; // one loop for both cases there
+                }
             }
             closest_hit<MODE>(A, geom, node_word, sphere_count, sphere_mask, ro, rd, rden, closest, best, st);
         }

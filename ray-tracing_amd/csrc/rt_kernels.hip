@@ -385,12 +385,14 @@ constexpr uint32_t kWaveTableWords = 88;
 // The kernel's argument struct as it lies in the kernel-argument segment (it is the only argument).
 // Blocks that run rarely read what they need from there instead of keeping it in scalar registers
 // through the whole trace loop, which is short of them; the empty asm keeps the compiler from
-// recognising the copy.
-__device__ __forceinline__ const TraceArgs& args_in_memory()
+// recognising the copy.  The pointer stays in the constant address space, so that the reads are scalar
+// loads (through a generic pointer they would be per-lane flat loads).
+typedef const __attribute__((address_space(4))) TraceArgs* KernelArgs;
+__device__ __forceinline__ KernelArgs args_in_memory()
 {
-    const void* segment = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto segment = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(segment));
-    return *reinterpret_cast<const TraceArgs*>(segment);
+    return (KernelArgs)segment;
 }
 
 // The next unit of the launch for this wave, from the counter the host zeroes before the launch.
@@ -410,27 +412,27 @@ __device__ __forceinline__ uint32_t next_unit(uint32_t* counter)
 __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, uint32_t unit, uint32_t* hash_tab)
 {
     (void)A_in_registers;
-    const TraceArgs& A = args_in_memory();
+    const KernelArgs A = args_in_memory();
     Unit u;
-    const uint32_t chunk = unit / A.n_tiles;
-    const uint32_t tile = unit - chunk * A.n_tiles;
-    const uint32_t tile_y = tile / A.tiles_x;
-    const uint32_t tile_x = tile - tile_y * A.tiles_x;
+    const uint32_t chunk = unit / A->n_tiles;
+    const uint32_t tile = unit - chunk * A->n_tiles;
+    const uint32_t tile_y = tile / A->tiles_x;
+    const uint32_t tile_x = tile - tile_y * A->tiles_x;
     // the pixel tile of a unit is 2^tile_w_log2 x 2^tile_h_log2, at most 8 x 8
-    u.x0 = tile_x << A.tile_w_log2;
-    u.y0 = A.row_begin + (tile_y << A.tile_h_log2);
-    u.tile_w = min(1u << A.tile_w_log2, A.width - u.x0);
-    u.tile_h = min(1u << A.tile_h_log2, A.row_end - u.y0);
+    u.x0 = tile_x << A->tile_w_log2;
+    u.y0 = A->row_begin + (tile_y << A->tile_h_log2);
+    u.tile_w = min(1u << A->tile_w_log2, A->width - u.x0);
+    u.tile_h = min(1u << A->tile_h_log2, A->row_end - u.y0);
     u.tile_pixels = u.tile_w * u.tile_h;
-    u.rel_begin = chunk * A.frames_per_unit;
-    const uint32_t rel_count = min(A.frames_per_unit, A.n_frames - u.rel_begin);
+    u.rel_begin = chunk * A->frames_per_unit;
+    const uint32_t rel_count = min(A->frames_per_unit, A->n_frames - u.rel_begin);
     u.n_items = u.tile_pixels * rel_count;
     const uint32_t lane = threadIdx.x & 63u;
     if (lane < 16u) {
         hash_tab[lane] = hash1(lane < 8u ? u.x0 + lane : u.y0 + lane - 8u);
     }
     if (lane < rel_count) {
-        hash_tab[16u + lane] = hash1(A.first_frame + (u.rel_begin + lane) * A.frame_stride);
+        hash_tab[16u + lane] = hash1(A->first_frame + (u.rel_begin + lane) * A->frame_stride);
     }
     if (lane == 0u) {
         hash_tab[kUnitWords + 0u] = u.x0;
@@ -696,9 +698,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         const uint32_t old_texel = texel;
         const uint32_t old_rel = rel;
         if (write_out) {
-            const TraceArgs& M = args_in_memory();
-            if (M.rng_out != nullptr && rel + 1u == M.n_frames) {
-                M.rng_out[texel] = rng;
+            const KernelArgs M = args_in_memory();
+            if (M->rng_out != nullptr && rel + 1u == M->n_frames) {
+                M->rng_out[texel] = rng;
             }
         }
         // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             // The pool is empty: on to the next unit.  No lane has left the loop yet (lanes leave only
             // when there are no more units), and the lanes still busy with items of the old unit hold
             // everything they need in registers.
-            unit = next_unit(args_in_memory().unit_counter);
+            unit = next_unit(args_in_memory()->unit_counter);
             if (unit < n_units) {
                 n_items = load_unit(A, unit, hash_tab);
                 next_item = 0;
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             const uint32_t px = unit_x0 + lx;
             const uint32_t py = unit_y0 + ly;
             rel = rel_begin + frame_in_chunk;
-            texel = py * args_in_memory().width + px;
+            texel = py * args_in_memory()->width + px;
             fpx = (float)(int32_t)px;
             fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
             rng = hash_tab[lx] ^ hash_tab[8u + ly] ^ hash_tab[16u + frame_in_chunk]; // :310-311
@@ -886,17 +888,17 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         st.phase_end(PH_SHADE);
         // ------------------------------------------------------------------ finished item, :333-335
         if (write_out) {
-            const TraceArgs& M = args_in_memory();
-            if (M.partial != nullptr) {
-                M.partial[(size_t)old_rel * ((size_t)M.width * M.height) + old_texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
+            const KernelArgs M = args_in_memory();
+            if (M->partial != nullptr) {
+                M->partial[(size_t)old_rel * ((size_t)M->width * M->height) + old_texel] = make_float4(frame_sum.x, frame_sum.y, frame_sum.z, 0.0f);
             } else {
-                const float4 prev = M.accum[old_texel];
+                const float4 prev = M->accum[old_texel];
                 const f3 total = mk(prev.x, prev.y, prev.z) + frame_sum;
-                M.accum[old_texel] = make_float4(total.x, total.y, total.z, 1.0f);
-                if (M.output != nullptr) {
+                M->accum[old_texel] = make_float4(total.x, total.y, total.z, 1.0f);
+                if (M->output != nullptr) {
                     // :337 (frame + 1u) * spp wraps in uint32 before the conversion
-                    const uint32_t frame = M.first_frame + old_rel * M.frame_stride;
-                    M.output[old_texel] = tonemap_rgba8(total, (float)((frame + 1u) * M.params.frame_sample_depth_count[1]));
+                    const uint32_t frame = M->first_frame + old_rel * M->frame_stride;
+                    M->output[old_texel] = tonemap_rgba8(total, (float)((frame + 1u) * M->params.frame_sample_depth_count[1]));
                 }
             }
             frame_sum = mk(0.0f, 0.0f, 0.0f);

@@ -119,7 +119,7 @@ struct WaveStats {
     }
     __device__ __forceinline__ void section(int k)
     {
-        unsigned long long m = __ballot(1);
+        unsigned long long m = __builtin_amdgcn_ballot_w64(true);
         lanes[k] += 1u;
         if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1)) {
             exec[k] += 1u;
@@ -193,6 +193,13 @@ __device__ __forceinline__ void stage_tree(const float4* __restrict__ node_geom,
         word[i] = node_word[i];
     }
     __syncthreads();
+}
+
+// Mask of the lanes for which `predicate` holds.  (__ballot takes an int: the predicate would be turned
+// into 0/1 by a select and compared with zero again, two vector instructions per ballot.)
+__device__ __forceinline__ unsigned long long wave_ballot(bool predicate)
+{
+    return __builtin_amdgcn_ballot_w64(predicate);
 }
 
 // Number of set bits of a wave mask below this lane.
@@ -327,9 +334,9 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
         }
     }
     // the round ends when fewer than this many lanes are still walking
-    const uint32_t in_loop = (uint32_t)__popcll(__ballot(true));
+    const uint32_t in_loop = (uint32_t)__popcll(wave_ballot(true));
     const uint32_t few = __builtin_amdgcn_readfirstlane(kWalkQuorum != 0u && in_loop > kWalkQuorum ? in_loop - kWalkQuorum : 0u);
-    if ((uint32_t)__popcll(__ballot(t.at < end)) <= few) {
+    if ((uint32_t)__popcll(wave_ballot(t.at < end)) <= few) {
         return;
     }
     // (bottom-tested by hand: the compiler does not rotate a loop whose test holds a ballot)
@@ -366,7 +373,7 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
             t.link = skip ? link_jump : link_seq;
             t.at = skip ? jump : seq;
         }
-    } while ((uint32_t)__popcll(__ballot(t.at < end)) > few);
+    } while ((uint32_t)__popcll(wave_ballot(t.at < end)) > few);
 }
 
 // A unit of work: a pixel tile x a chunk of frames, pooled by one wave.  Its description lives in
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                                 dot(w, dc) + len_w * rho + (0.002f * len_w + lens) * len_dc < 0.0f;
             keep = !(misses || behind);
         }
-        camera_mask = (uint32_t)__ballot(keep);
+        camera_mask = (uint32_t)wave_ballot(keep);
     }
 
     // ---- per-lane state ----
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         rden.a_ok = true;
         rden.bounded = false;
         bool traced = live; // the lane's segment has been searched to its end in this iteration
-        if (Stats::kEnabled && live && __ballot(live && depth != 0u) == 0ull) {
+        if (Stats::kEnabled && live && wave_ballot(live && depth != 0u) == 0ull) {
             st.section(ST_ALL_PRIMARY); // every ray of the wave in this iteration is a camera ray
         }
         if (TREE) {
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             if (CULL) {
                 // (the loop over a mask is 1.4 % slower than the counted loop when it has to visit every
                 // sphere anyway, so it is only used with a reduced mask)
-                sphere_mask = __ballot(live && depth != 0u) == 0ull && camera_mask != full_mask ? camera_mask : 0xFFFFFFFFu;
+                sphere_mask = wave_ballot(live && depth != 0u) == 0ull && camera_mask != full_mask ? camera_mask : 0xFFFFFFFFu;
                 if (MODE == kFullLds5) {
                     sphere_mask &= 31u; // one loop for both cases there
                 }
@@ -689,8 +696,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         // (not with the hierarchy: there a waiting lane idles through a walk of a hundred nodes, which
         // costs more than the blocks it would share are worth -- measured 65.3 against 62.4 ms on one box)
         if (kRegenQuorum != 0u && !TREE) {
-            const unsigned long long done_mask = __ballot(path_done);
-            const unsigned long long in_loop = __ballot(true);
+            const unsigned long long done_mask = wave_ballot(path_done);
+            const unsigned long long in_loop = wave_ballot(true);
             regen = path_done && ((uint32_t)__popcll(done_mask) >= kRegenQuorum || done_mask == in_loop);
         }
         const bool need_item = regen && samples_left == 0u;
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             }
         }
         // Every lane still in the loop runs the pool arithmetic, so the cursor stays wave-uniform.
-        const unsigned long long want = __ballot(need_item);
+        const unsigned long long want = wave_ballot(need_item);
         if (PERSISTENT && want != 0ull && next_item >= n_items && more_units) {
             // The pool is empty: on to the next unit.  No lane has left the loop yet (lanes leave only
             // when there are no more units), and the lanes still busy with items of the old unit hold
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             const uint32_t add3 = is3 & 1013904223u;
             const uint32_t mask3 = is3 & 0x00FFFFFFu;
             const int32_t off3 = (int32_t)(is3 & 0x00800000u);
-            if (__ballot(want3) == 0ull) {
+            if (wave_ballot(want3) == 0ull) {
                 // only camera lanes in this wave (a tile of sky, typically): two draws per candidate
                 do {
                     st.section(ST_DISK_IT);

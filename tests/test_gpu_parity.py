@@ -361,6 +361,30 @@ def test_full_1080p_frame_bit_exact(pkg, oracle):
     t.destroy()
 
 
+def test_benchmark_batch_equals_frame_by_frame_at_full_size(pkg):
+    """The benchmark workload itself (1920x1080, 16 spp, depth 8, DoF off, 64 frames in one launch: 2 x 4
+    pixel tiles, per-frame sums folded in order) against 64 single-frame launches (8 x 8 tiles, direct
+    accumulation), whose first frame test_full_1080p_frame_bit_exact pins to the oracle; and against two
+    row shards of the same batch."""
+    batch = make_tracer(pkg, 1920, 1080, 16, 8, 0.0)
+    batch.enable_rng_capture(True)
+    batch.render_frames(0, 64)
+    single = make_tracer(pkg, 1920, 1080, 16, 8, 0.0)
+    single.enable_rng_capture(True)
+    for f in range(64):
+        single.render(f)
+    assert same(batch.read_rng_state(), single.read_rng_state())
+    assert same(batch.read_accum(), single.read_accum())
+    assert same(batch.read_output(), single.read_output())
+    single.destroy()
+    shards = make_tracer(pkg, 1920, 1080, 16, 8, 0.0)
+    shards.render_shard(0, 64, 1, 0, 541, write_output=False)
+    shards.render_shard(0, 64, 1, 541, 1080, write_output=False)
+    assert same(batch.read_accum(), shards.read_accum())
+    shards.destroy()
+    batch.destroy()
+
+
 def test_converged_radiance_properties(pkg, oracle):
     # size-independent checks at 4096 spp on a small image: alpha is 1, radiance is finite and
     # non-negative, and the mean luminance agrees with an independent 256-spp oracle render of

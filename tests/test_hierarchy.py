@@ -486,3 +486,14 @@ def test_scenes_beyond_lds(pkg, oracle, count):
     assert same(results[0][1], ref["rng"])
     assert same(results[0][0], ref["accum"])
     assert same(results[0][2], ref["output"])
+
+
+@pytest.mark.gpu
+def test_4096_spheres_at_full_size(pkg):
+    """The 4096-sphere configuration at its full size (1920x1080, 16 spp, depth 50, one frame): the
+    hierarchy kernel (persistent waves, resumable walks) against the loop over all spheres."""
+    scene = pkg.synthetic_scene(4096)
+    a = _render(pkg, scene, True, w=1920, h=1080, spp=16, depth=50, frames=1)
+    b = _render(pkg, scene, False, w=1920, h=1080, spp=16, depth=50, frames=1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))

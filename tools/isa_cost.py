@@ -29,7 +29,7 @@ def cost(op, operands=''):
 
 def main():
     path = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else 'rt_trace_kernelILi1ENS0_7NoStats'
+    want = sys.argv[2] if len(sys.argv) > 2 else 'rt_trace_kernelILi5ENS0_7NoStats'
     text = open(path).read().split('\n')
     inside = False
     blocks = []

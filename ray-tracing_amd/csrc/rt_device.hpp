@@ -113,7 +113,11 @@ __device__ __forceinline__ float inversesqrt(float x)
 {
     // 2^-40 <= x <= 2^40 keeps both the sqrt and the reciprocal of its result inside the cheap ranges
     float s = sqrt_core(x);
-    float q = div_core(1.0f, s, refined_rcp(s));
+    // 1 / s: on gfx950 v_rcp_f32 and one Newton step give the correctly rounded reciprocal of every s
+    // that can occur here (tools/exhaustive_inversesqrt.py compares this function with the full
+    // sequences for every binary32 x in [2^-40, 2^40]: no difference in 671 088 641 values; a residual
+    // step on top changes nothing)
+    float q = refined_rcp(s);
     if (!(x >= 0x1p-40f && x <= 0x1p40f)) {
         RT_COLD_PATH();
         q = 1.0f / sqrtf(x);

@@ -131,6 +131,17 @@ def test_cheap_divide_and_sqrt_are_correctly_rounded(pkg):
         np.seterr(**old)
 
 
+def test_inversesqrt_over_its_whole_short_range(pkg):
+    """Every 16th binary32 value of [2^-40, 2^40] (tools/exhaustive_inversesqrt.py runs all of them): the
+    kernel's inversesqrt against the full IEEE sqrt and division sequences on the device."""
+    lo = np.float32(2.0 ** -40).view(np.uint32).item()
+    hi = np.float32(2.0 ** 40).view(np.uint32).item()
+    for start in range(lo, hi + 1, 1 << 28):
+        bits = np.arange(start, min(start + (1 << 28), hi + 1), 16, dtype=np.uint32)
+        cheap, full = pkg.probe_arith(2, bits.view(np.float32))
+        assert np.array_equal(cheap.view(np.uint32), full.view(np.uint32))
+
+
 def test_hit_sphere_vectors(pkg, oracle):
     rng = np.random.default_rng(7)
     n = 6000

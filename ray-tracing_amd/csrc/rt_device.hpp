@@ -51,7 +51,19 @@ constexpr float kDenHi = 0x1p20f;
 constexpr float kNumLo = 0x1p-90f;  // numerators with 2^-90 <= |n| < 2^100
 constexpr float kNumHi = 0x1p100f;
 
-__device__ __forceinline__ bool den_in_range(float d) { return d >= kDenLo && d <= kDenHi; }
+// lo <= x <= hi for positive finite lo <= hi, as one unsigned comparison of bit patterns (positive floats
+// order like their bits; a negative x, a NaN or an infinity above hi falls outside like in the two
+// float comparisons).
+__device__ __forceinline__ bool in_closed_range(float x, float lo, float hi)
+{
+    return __float_as_uint(x) - __float_as_uint(lo) <= __float_as_uint(hi) - __float_as_uint(lo);
+}
+// lo <= x < hi
+__device__ __forceinline__ bool in_half_open_range(float x, float lo, float hi)
+{
+    return __float_as_uint(x) - __float_as_uint(lo) < __float_as_uint(hi) - __float_as_uint(lo);
+}
+__device__ __forceinline__ bool den_in_range(float d) { return in_closed_range(d, kDenLo, kDenHi); }
 __device__ __forceinline__ bool num_in_range(float n) { return fabsf(n) >= kNumLo && fabsf(n) < kNumHi; }
 
 // Denominator half of the division sequence: rcp and one Newton step.
@@ -102,7 +114,7 @@ __device__ __forceinline__ float sqrt_core(float x)
 __device__ __forceinline__ float sqrt_exact(float x)
 {
     float s = sqrt_core(x);
-    if (!(x >= kNumLo && x < kNumHi)) {
+    if (!in_half_open_range(x, kNumLo, kNumHi)) {
         RT_COLD_PATH();
         s = sqrtf(x);
     }
@@ -118,7 +130,7 @@ __device__ __forceinline__ float inversesqrt(float x)
     // sequences for every binary32 x in [2^-40, 2^40]: no difference in 671 088 641 values; a residual
     // step on top changes nothing)
     float q = refined_rcp(s);
-    if (!(x >= 0x1p-40f && x <= 0x1p40f)) {
+    if (!in_closed_range(x, 0x1p-40f, 0x1p40f)) {
         RT_COLD_PATH();
         q = 1.0f / sqrtf(x);
     }

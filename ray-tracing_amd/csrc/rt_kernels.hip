@@ -24,6 +24,9 @@
 //
 // The sphere list is staged once per workgroup in LDS as (centre, radius^2) float4 records read at
 // a wave-uniform address (broadcast); material records are fetched only for the winning sphere.
+// Scenes of up to 16 spheres: iterations in which every ray of the wave is a camera ray of the wave's
+// own pixel tile test only the spheres that tile can see; the kernel for exactly five spheres (the
+// reference's scene) has its sphere loop unrolled.
 //
 // Scenes of kTreeMinSpheres spheres or more are traced through a bounding-sphere hierarchy
 // (rt_tree.hpp): each lane walks the depth-first node array on its own, one node per trip, and a

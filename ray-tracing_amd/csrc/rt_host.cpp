@@ -292,6 +292,16 @@ int upload_scene(rt_tracer* h, hipStream_t stream)
         if (h->tree.packed()) {
             words = h->tree.word;
             words.push_back(0u);
+            // the LDS walk reads an inner node's continuation from its fourth float: sign bit set, the
+            // value rounded up to a multiple of 2^13 ulps, the node index in the 13 bits that frees
+            for (uint32_t i = 0; i < nodes; ++i) {
+                if (h->tree.sphere[i] == rt::kTreeNoSphere) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &geom[4u * i + 3u], sizeof bits);
+                    bits = ((bits + 0x1FFFu) & ~0x1FFFu) | h->tree.link[i] | 0x80000000u;
+                    std::memcpy(&geom[4u * i + 3u], &bits, sizeof bits);
+                }
+            }
         } else {
             words.resize((static_cast<size_t>(nodes) + 1u) * 2u, 0u);
             for (uint32_t i = 0; i < nodes; ++i) {

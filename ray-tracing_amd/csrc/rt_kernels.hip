@@ -346,35 +346,58 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
     do {
         if (t.at < end) {
             st.section(ST_NODE);
-            const float4 g = t.g;
-            const uint32_t w = t.w;
             // The node after this one is either the next in the array or the one behind this node's
-            // subtree (for a leaf the two coincide); both are fetched now, so that the LDS latency passes
-            // while this node is tested.  Behind the last node both offsets point at the first bytes after
-            // the arrays they index, still inside the workgroup's LDS, and what is read there is not used.
+            // subtree (for a leaf the two coincide); both are fetched now, so that the memory latency
+            // passes while this node is tested.  Behind the last node both offsets point at the first
+            // bytes after the arrays they index (inside the workgroup's LDS, or the spare entry of the
+            // arrays in global memory), and what is read there is not used.
             const uint32_t seq = t.at + 16u;
-            const uint32_t jump = t.link;
-            const float4 g_seq = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + seq);
-            const float4 g_jump = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + jump);
-            uint32_t w_seq, link_seq, w_jump, link_jump;
-            load_node_words<WIDE>(node_word, seq, w_seq, link_seq);
-            load_node_words<WIDE>(node_word, jump, w_jump, link_jump);
-            // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
-            const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
-            const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, t.rden.a, k);
-            // A ball (radius R, centre at distance D from the origin) lies wholly beyond the closest
-            // hit so far when D > L + R, L = closest * |d|; D^2 - 2 R^2 > 2.5 L^2 implies D > 1.05 (L + R),
-            // which no rounding here comes near, so every root inside the ball exceeds `closest`.
-            const bool skip = q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit;
-            if (!skip && (int32_t)w < 0) {
-                sphere_closest_any_order(q, t.rden, kTMin, (int)((w & ~kTreeLeafFlag) >> (WIDE ? 0u : kTreeIndexShift)), t.closest,
-                                         t.best, st);
-                t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
+            if (WIDE) {
+                const float4 g = t.g;
+                const uint32_t w = t.w;
+                const uint32_t jump = t.link;
+                const float4 g_seq = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + seq);
+                const float4 g_jump = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + jump);
+                uint32_t w_seq, link_seq, w_jump, link_jump;
+                load_node_words<WIDE>(node_word, seq, w_seq, link_seq);
+                load_node_words<WIDE>(node_word, jump, w_jump, link_jump);
+                // dot(oc,oc) is scaled by 1 - 2^-13 for an internal node and by exactly 1 for a leaf
+                const float k = __uint_as_float(0x3F7FF800u + ((w >> 20) & 0x800u));
+                const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, t.rden.a, k);
+                // A ball (radius R, centre at distance D from the origin) lies wholly beyond the closest
+                // hit so far when D > L + R, L = closest * |d|; D^2 - 2 R^2 > 2.5 L^2 implies D > 1.05 (L + R),
+                // which no rounding here comes near, so every root inside the ball exceeds `closest`.
+                const bool skip = q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit;
+                if (!skip && (int32_t)w < 0) {
+                    sphere_closest_any_order(q, t.rden, kTMin, (int)(w & ~kTreeLeafFlag), t.closest, t.best, st);
+                    t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
+                }
+                t.g = skip ? g_jump : g_seq;
+                t.w = skip ? w_jump : w_seq;
+                t.link = skip ? link_jump : link_seq;
+                t.at = skip ? jump : seq;
+            } else {
+                // In LDS the fourth float of an inner node carries its sign bit set and, in the low 13 bits
+                // of its mantissa, the index of the node to continue at (rt_host.cpp packs it; the value
+                // is w rounded up, so the test only gets more cautious); a leaf's is r^2 as it is.  The
+                // word array is read for the sphere index of a leaf that has to be resolved, nothing else.
+                const uint32_t bits = __float_as_uint(t.g.w);
+                const bool inner = (int32_t)bits < 0;
+                const float4 g = make_float4(t.g.x, t.g.y, t.g.z, __uint_as_float(bits & 0x7FFFFFFFu));
+                const uint32_t jump = inner ? (bits & 0x1FFFu) << 4 : seq;
+                const float4 g_seq = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + seq);
+                const float4 g_jump = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(geom) + jump);
+                const float k = __uint_as_float(0x3F800000u - ((bits >> 20) & 0x800u));
+                const SphereQuadratic q = sphere_quadratic_scaled(g, ro, rd, t.rden.a, k);
+                const bool skip = q.discriminant < 0.0f || behind_origin(q.half_b, q.c) || q.c - g.w > t.beyond_limit;
+                if (!skip && !inner) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(node_word) + (t.at >> 2));
+                    sphere_closest_any_order(q, t.rden, kTMin, (int)((w & ~kTreeLeafFlag) >> kTreeIndexShift), t.closest, t.best, st);
+                    t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
+                }
+                t.g = skip ? g_jump : g_seq;
+                t.at = skip ? jump : seq;
             }
-            t.g = skip ? g_jump : g_seq;
-            t.w = skip ? w_jump : w_seq;
-            t.link = skip ? link_jump : link_seq;
-            t.at = skip ? jump : seq;
         }
     } while ((uint32_t)__popcll(wave_ballot(t.at < end)) > few);
 }

@@ -19,6 +19,9 @@
 // A ray visits node i; if the node's test fails it continues at the offset in the word, otherwise
 // at i + 1 (the first child, or simply the next node after a leaf).
 //
+// (The copy in device memory of such a tree also carries an inner node's continuation index in the low
+// 13 mantissa bits of w, rounded up first, with the sign bit set: rt_host.cpp, tree_walk.)
+//
 // Trees too large for those bit fields (more than kTreeMaxNodes nodes) keep two words per node
 // instead: the byte offset of the node to continue at, and 1<<31 | sphere index (0 for an internal
 // node); such trees are walked in global memory.

@@ -48,8 +48,10 @@ constexpr uint32_t kTreeMinSpheres = RT_TREE_MIN_SPHERES;
 constexpr uint32_t kTreeLeafFlag = 0x80000000u;
 constexpr uint32_t kTreeOffsetMask = 0x0001FFFFu;
 constexpr uint32_t kTreeIndexShift = 17;
-// Most nodes a tree may have: offsets are 17 bits of bytes / 16.
-constexpr uint32_t kTreeMaxNodes = 8191;
+// Most nodes a tree in the packed format may have: offsets are 17 bits of bytes / 16 (8191), and
+// 20 bytes per node plus the hash tables of sixteen waves have to fit the 160 KiB of LDS of a
+// compute unit.
+constexpr uint32_t kTreeMaxNodes = 7900;
 
 // Largest scene a hierarchy is built for (byte offsets of nodes stay below 2^32 with room to spare).
 constexpr uint32_t kTreeMaxSpheres = 1u << 20;

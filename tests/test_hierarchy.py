@@ -72,7 +72,7 @@ def test_structure(pkg, name):
              "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
     t = _host(pkg, scene)
     geom, word = t.get_scene_hierarchy()
-    assert 0 < len(word) <= 8191
+    assert 0 < len(word) <= 7900
     _check_structure(scene, geom, word)
     # the same scene gives the same hierarchy
     t2 = _host(pkg, scene)
@@ -453,7 +453,7 @@ def test_links_agree_with_packed_words_and_cover_large_scenes(pkg):
     big = pkg.synthetic_scene(9000)
     t.set_spheres(big)
     geom, link, sphere = t.get_scene_hierarchy_links()
-    assert len(link) > 8191                      # beyond the packed format
+    assert len(link) > 7900                      # beyond the packed format
     _check_links(big, geom, link, sphere)
     with pytest.raises(RuntimeError, match="too large for packed"):
         t.get_scene_hierarchy()
@@ -495,5 +495,26 @@ def test_4096_spheres_at_full_size(pkg):
     scene = pkg.synthetic_scene(4096)
     a = _render(pkg, scene, True, w=1920, h=1080, spp=16, depth=50, frames=1)
     b = _render(pkg, scene, False, w=1920, h=1080, spp=16, depth=50, frames=1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_largest_tree_kept_in_lds(pkg):
+    """A scene whose hierarchy is just below the node limit of the packed format: its nodes and the hash
+    tables of sixteen waves must fit the LDS of a compute unit."""
+    count = 5600
+    scene = pkg.synthetic_scene(count)
+    t = _host(pkg, scene)
+    nodes = len(t.get_scene_hierarchy_links()[1])
+    while nodes > 7900:
+        count -= 50
+        scene = pkg.synthetic_scene(count)
+        t.set_spheres(scene)
+        nodes = len(t.get_scene_hierarchy_links()[1])
+    assert nodes > 7600 and len(t.get_scene_hierarchy()[1]) == nodes      # packed
+    t.destroy()
+    a = _render(pkg, scene, True, w=64, h=40, spp=1, depth=4, frames=2)
+    b = _render(pkg, scene, False, w=64, h=40, spp=1, depth=4, frames=2)
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))

@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the traced path: path samples/sec at 1080p, depth 8.
 
-One "step" renders the batch the headline metric is quoted on: the default five-sphere scene at
-1920x1080, 16 samples per pixel per frame, depth 8, depth of field off, 64 accumulated frames
-(2.12e9 path samples) -- one launch of the trace kernel per rank.  With --gpus N > 1 the frame
-indices are interleaved over the ranks (each rank still renders 64 frames of the full image, i.e.
-per-GPU work is fixed: weak scaling), followed by the step's real exchange: an RCCL sum all-reduce of
-the float4 accumulators and the display resolve of the reduced image.
+One "step" renders the batch the headline metric is quoted on (workload c2): the default five-sphere
+scene at 1920x1080, 16 samples per pixel per frame, depth 8, depth of field off, 64 accumulated frames
+(2.12e9 path samples).  On one GPU that is one launch of the trace kernel per step.
 
-Prints ONE JSON line on rank 0.
+With --gpus N > 1 one process per GPU shares each step (strong scaling by default: the step's work is
+fixed, N ranks split it) in one of the two ways the path shards:
+
+  --mode tiles   (default)  interleaved row stripes of the image, every rank renders all frames of its
+                            stripes, then ONE all_gather_into_tensor of the float4 accumulator shards
+                            (RCCL) and the display resolve.  Bit-identical to one GPU.
+  --mode frames             interleaved frame indices of the whole image, then a sum all-reduce of the
+                            float4 accumulators, alpha back to 1, and the display resolve.
+
+The collective and the resolve are inside the timed region.  --scaling weak (frames mode only) keeps 64
+frames per rank instead.  --workload picks the other configurations: c3 (4K, 64 spp, depth 16, DoF on,
+64 frames), c4 (8K, 256 spp, one frame; meant for --mode tiles), c5 (4096 spheres, depth 50, 8 frames;
+meant for --mode frames).
+
+Launch: `python bench.py --gpus N` starts its N rank processes itself; under a torch.distributed
+launcher (WORLD_SIZE set) it is one of the ranks.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,23 +34,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT, SPP, DEPTH, FRAMES = 1920, 1080, 16, 8, 64
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32: 256 CU x 256 FLOP/clk x 2.4 GHz
 
+WORKLOADS = {
+    # the configuration the metric is quoted on
+    "c2": dict(width=1920, height=1080, spp=16, depth=8, aperture=0.0, frames=64, scene="default",
+               flops_key="c2_1080p_spp16_depth8_dof_off",
+               text="default 5-sphere scene, 1920x1080, 16 spp/frame, depth 8, DoF off, 64 accumulated frames"),
+    "c3": dict(width=3840, height=2160, spp=64, depth=16, aperture=0.05, frames=64, scene="default",
+               flops_key="c3_4k_spp64_depth16_dof_on",
+               text="default 5-sphere scene, 3840x2160, 64 spp/frame, depth 16, DoF on, 64 accumulated frames (4096 spp)"),
+    "c4": dict(width=7680, height=4320, spp=256, depth=8, aperture=0.05, frames=1, scene="default",
+               flops_key="c4_8k_spp256_depth8_dof_on",
+               text="default 5-sphere scene, 7680x4320, 256 spp, depth 8, DoF on, one frame"),
+    "c5": dict(width=1920, height=1080, spp=16, depth=50, aperture=0.05, frames=8, scene="synthetic4096",
+               flops_key="c5_4096_spheres_depth50",
+               text="synthetic 4096-sphere mixed-material scene, 1920x1080, 16 spp/frame, depth 50, 8 frames"),
+}
 
-def load_flops_per_sample():
-    """Algorithmic FLOP per path sample of this workload, from the instrumented oracle's event counters
-    (profiles/flops_per_sample.json, produced by tools/count_flops.py)."""
+
+def load_flops_per_sample(key):
+    """Algorithmic FLOP per path sample of a workload, from the instrumented oracle's event counters
+    (profiles/flops_per_sample.json, produced by tools/count_flops.py); None if not recorded."""
     path = os.path.join(ROOT, "profiles", "flops_per_sample.json")
     with open(path) as f:
-        return json.load(f)["c2_1080p_spp16_depth8_dof_off"]["flops_per_sample"]
+        rec = json.load(f).get(key)
+    return rec["flops_per_sample"] if rec else None
 
 
 def load_measured_traffic():
-    """HBM bytes per trace launch from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE); None if not recorded.
+    """HBM bytes per trace launch of the c2 workload from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE); None if not recorded.
     Profiles of this command live in profiles/r<round><letter>/; directories with a suffix
-    (r1i_c5m ...) hold other workloads."""
+    (r1i_c5m ...) hold other workloads.  The most recent one wins."""
     import re
     best = None
     base = os.path.join(ROOT, "profiles")
@@ -49,81 +79,170 @@ def load_measured_traffic():
     return best
 
 
-def cpu_baseline(pkg, frames=24):
-    """The CPU oracle (a port of the reference shader) timed on this machine's host cores on a bounded
-    sample of the same workload."""
+def host_threads():
+    """Threads for the CPU baseline: every core this process may run on (its affinity mask; the machine's
+    core count can be many times that on a shared box), bounded by OMP_NUM_THREADS where the environment
+    sets a share."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit() and int(share) > 0:
+        allowed = min(allowed, int(share))
+    return max(1, min(allowed, 256)), (os.cpu_count() or 1)
+
+
+def cpu_baseline(pkg, wl, budget_s=10.0):
+    """The CPU oracle (a port of the reference shader) timed on this machine's host cores: as many frames
+    of the benchmark workload as fit the time budget, and BASELINE.json's own CPU-runnable case (1280x720,
+    1 spp, depth 8) next to it."""
     from oracle import pyoracle
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
-    host = pkg.RayTracer().create(WIDTH, HEIGHT, device_id=-1)
-    host.set_samples_per_pixel(SPP)
-    host.set_max_depth(DEPTH)
-    host.set_aperture(0.0)
+    threads, machine = host_threads()
     scene = pkg.default_scene()
-    accum = None
-    t0 = time.perf_counter()
-    for f in range(frames):
-        accum = pyoracle.render(host.get_params_words(f), scene, accum=accum, want_output=False,
-                                nthreads=threads)["accum"]
-    dt = time.perf_counter() - t0
-    samples = WIDTH * HEIGHT * SPP * frames
-    return {"value": samples / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "frames 0..%d of the same 1080p/16spp/depth-8 workload (%.3g samples, %.1f s)" % (
-                frames - 1, samples, dt)}
+
+    def run(width, height, spp, depth, aperture, min_frames, seconds):
+        host = pkg.RayTracer().create(width, height, device_id=-1)
+        host.set_samples_per_pixel(spp)
+        host.set_max_depth(depth)
+        host.set_aperture(aperture)
+        accum = None
+        frames = 0
+        t0 = time.perf_counter()
+        while frames < min_frames or time.perf_counter() - t0 < seconds:
+            accum = pyoracle.render(host.get_params_words(frames), scene, accum=accum, want_output=False,
+                                    nthreads=threads)["accum"]
+            frames += 1
+        dt = time.perf_counter() - t0
+        host.destroy()
+        return width * height * spp * frames / dt, frames, dt
+
+    rate, frames, dt = run(wl["width"], wl["height"], wl["spp"], wl["depth"], wl["aperture"], 2, budget_s)
+    c1_rate, c1_frames, c1_dt = run(1280, 720, 1, 8, 0.05, 8, 1.0)
+    return {"value": rate, "unit": "samples/s", "cores": threads, "host_cpus": machine, "kind": "port",
+            "sample": "frames 0..%d of the same workload (%.3g samples, %.1f s, %d threads of %d host CPUs)" % (
+                frames - 1, wl["width"] * wl["height"] * wl["spp"] * frames, dt, threads, machine),
+            "c1": {"value": c1_rate, "unit": "samples/s",
+                   "sample": "1280x720, 1 spp, depth 8, aperture 0.05, frames 0..%d (%.2f s)" % (c1_frames - 1, c1_dt)}}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """Starts the N rank processes of this script (this process has not touched the GPU and never does)
+    and relays rank 0's output."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--mode", choices=["tiles", "frames"], default="tiles", help="how N > 1 ranks share a step")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--stripe-rows", type=int, default=0, help="rows per interleaved stripe in tiles mode (0: 4, or 16 at 8K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true",
-                    help="run the multi-GPU code path (process group, all-reduce, resolve) even with one rank")
+                    help="run the multi-GPU code path (process group, collective, resolve) even with one rank")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
-    import torch
-    import rtamd_loader
-    pkg = rtamd_loader.load()
-    from raytracing_amd import dist as rtdist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs a torch.distributed launch with that many ranks" % args.gpus)
+        sys.exit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    wl = WORKLOADS[args.workload]
     distributed = world > 1 or args.force_distributed
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.scaling == "weak" and args.mode != "frames":
+        sys.exit("--scaling weak needs --mode frames (a fixed image cannot grow with the ranks)")
+
+    import rtamd_loader
+    pkg = rtamd_loader.load()
+
+    # the CPU leg first: it needs no GPU, and the GPU then works until the end of the run
+    baseline = None
+    if rank == 0 and world == 1 and not args.force_distributed and not args.no_cpu_baseline:
+        baseline = cpu_baseline(pkg, wl)
+
+    import torch
+    from raytracing_amd import dist as rtdist
+    device_index = 0 if args.same_device else local_rank
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    tracer = pkg.RayTracer().create(WIDTH, HEIGHT, device_id=local_rank)
-    tracer.set_samples_per_pixel(SPP)
-    tracer.set_max_depth(DEPTH)
-    tracer.set_aperture(0.0)  # depth of field off; the lens draws are still consumed
+    width, height, spp, frames = wl["width"], wl["height"], wl["spp"], wl["frames"]
+    tracer = pkg.RayTracer().create(width, height, device_id=device_index)
+    tracer.set_samples_per_pixel(spp)
+    tracer.set_max_depth(wl["depth"])
+    tracer.set_aperture(wl["aperture"])  # 0 = depth of field off; the lens draws are still consumed
+    if wl["scene"] == "synthetic4096":
+        tracer.set_spheres(pkg.synthetic_scene(4096))
+        tracer.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
     stream = torch.cuda.current_stream(device)
     tracer.set_stream(stream.cuda_stream)
 
+    stripe_rows = args.stripe_rows or (16 if height >= 4000 else 4)
     accum = rtdist.accum_tensor(tracer, device) if distributed else None
-    reduced = torch.empty_like(accum) if distributed else None
+    reduced = torch.empty_like(accum) if distributed and args.mode == "frames" else None
+    frames_per_step = frames * world if args.scaling == "weak" else frames
 
     def step(index):
-        # rank r renders frames base + r, base + r + world, ... (64 of them)
-        base = index * FRAMES * world
-        first, count, stride = rtdist.frame_shard(base, FRAMES, world, rank)
-        tracer.render_shard(first, count, stride, 0, HEIGHT, write_output=not distributed)
-        if distributed:
+        base = index * frames_per_step
+        if not distributed:
+            tracer.render_frames(base, frames)
+        elif args.mode == "tiles":
+            # rank r: stripes r, r + world, ... of every frame of the step; then the image is put together
+            tracer.render_stripes(base, frames, 1, stripe_rows, rank, world, write_output=False)
+            rtdist.gather_stripes(accum, stripe_rows)
+            tracer.resolve_output((base + frames) * spp)
+        else:
+            # rank r: frames base + r, base + r + world, ... of the whole image; then the partial sums are added
+            count = len(range(rank, frames_per_step, world))
+            if count:
+                tracer.render_shard(base + rank, count, world, 0, height, write_output=False)
             rtdist.reduce_frame_split(accum, out=reduced)
-            total_frames = (index + 1) * FRAMES * world
-            tracer.resolve_output_from(reduced.data_ptr(), total_frames * SPP)
+            tracer.resolve_output_from(reduced.data_ptr(), (base + frames_per_step) * spp)
 
     def fence():
         if distributed:
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[device_index])
+            else:
+                torch.cuda.synchronize(device)
+                dist.barrier()
         torch.cuda.synchronize(device)
 
     for i in range(args.warmup):
@@ -137,20 +256,39 @@ def main():
     # GPU time of each timed step's trace launch: the library brackets every launch with HIP events
     # on the launch stream; reading them after the fence does not perturb the timed region
     kernel_ms = [tracer.kernel_ms(i) for i in range(min(args.steps, 64))]
+    kernel_ms = [k for k in kernel_ms if k >= 0.0]
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the spread of the ranks' kernel times is the load imbalance of the split
+        k = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=device)
+        k_max, k_min = k.clone(), k.clone()
+        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k_min, op=dist.ReduceOp.MIN)
+        kernel_spread = (float(k_min.item()), float(k_max.item()))
 
-    samples_per_rank_step = WIDTH * HEIGHT * SPP * FRAMES
-    total_samples = samples_per_rank_step * world * args.steps
-    value = total_samples / elapsed
+    samples_per_step = width * height * spp * frames_per_step
+    value = samples_per_step * args.steps / elapsed
 
     if rank == 0:
-        flops_per_sample = load_flops_per_sample()
+        flops_per_sample = load_flops_per_sample(wl["flops_key"])
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
-        achieved = flops_per_sample * samples_per_rank_step / avg_kernel_s / 1e12
+        # samples this rank's launch traced (its share of the step)
+        if not distributed:
+            launch_samples = samples_per_step
+        elif args.mode == "tiles":
+            my_rows = sum(min(height, (s + 1) * stripe_rows) - s * stripe_rows
+                          for s in rtdist.stripes_of_rank(height, stripe_rows, world, rank))
+            launch_samples = width * my_rows * spp * frames
+        else:
+            launch_samples = width * height * spp * len(range(rank, frames_per_step, world))
+        if distributed:
+            how = ("interleaved %d-row stripes x%d + RCCL all-gather of the accumulator" % (stripe_rows, world)
+                   if args.mode == "tiles" else "frame-index split x%d + RCCL sum all-reduce of the accumulator" % world)
+        else:
+            how = "1 GPU"
         result = {
             "metric": "path samples/sec at 1080p depth 8",
             "value": value,
@@ -160,24 +298,34 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "default 5-sphere scene, 1920x1080, 16 spp/frame, depth 8, DoF off, "
-                                   "64 accumulated frames per GPU per step",
-                       "parallelism": "frame-index split x%d + RCCL sum all-reduce" % world if distributed else "1 GPU",
-                       "samples_per_step": samples_per_rank_step * world},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": load_measured_traffic(),
-                         "kernel_ms": avg_kernel_s * 1e3, "flops_per_sample": flops_per_sample,
-                         "note": "FP32 VALU-bound kernel (no MFMA; HBM traffic is the 16 B per-frame sum per pixel "
-                                 "per frame, ~2.1 GB per launch, i.e. ~50 GB/s); achieved = algorithmic FLOP per launch / "
-                                 "HIP-event kernel time; traffic = bytes per launch from the committed rocprofv3 PMC passes"},
+            "config": {"workload": "%s: %s" % (args.workload, wl["text"]) +
+                                   (" per GPU" if args.scaling == "weak" and world > 1 else " per step"),
+                       "parallelism": how,
+                       "samples_per_step": samples_per_step},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(pkg)
-        print(json.dumps(result))
+        if flops_per_sample is not None:
+            achieved = flops_per_sample * launch_samples / avg_kernel_s / 1e12
+            result["roofline"] = {
+                "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "traffic": load_measured_traffic() if args.workload == "c2" and not distributed else None,
+                "kernel_ms": avg_kernel_s * 1e3, "flops_per_sample": flops_per_sample,
+                "note": "FP32 VALU-bound kernel (no MFMA; HBM traffic is the 16 B per-frame sum per pixel per frame, "
+                        "i.e. well under 100 GB/s); achieved = algorithmic FLOP per launch / HIP-event kernel time of "
+                        "rank 0's launch; traffic = bytes per launch from the committed rocprofv3 PMC passes"}
+        else:
+            result["roofline"] = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": None, "traffic": None, "kernel_ms": avg_kernel_s * 1e3,
+                                  "note": "no algorithmic FLOP count recorded for this workload (tools/count_flops.py)"}
+        if distributed:
+            result["rank_kernel_ms"] = {"min": kernel_spread[0], "max": kernel_spread[1]}
+        if baseline is not None:
+            result["cpu_baseline"] = baseline
+        print(json.dumps(result), flush=True)
 
     tracer.destroy()
     if distributed:

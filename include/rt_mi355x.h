@@ -7,7 +7,11 @@
  * (shaders/raytrace.comp.glsl).  Every entry point below names the reference
  * interface it stands in for.  All functions return 0 on success or a
  * non-zero rt_status; nothing throws across this boundary.  A handle is used
- * from one thread at a time; one handle drives one GPU.
+ * from one thread at a time and from one stream at a time (a call on another
+ * stream must be ordered after the handle's earlier work by the caller: the
+ * launches of one handle share its accumulator, its per-frame sums and its unit
+ * counter); one handle drives one GPU.  A call that fails leaves the handle's
+ * extent, images and scene as they were before the call.
  *
  * Images are linear row-major, row 0 = top, pitch = width: the accumulator is
  * float4 per pixel (the rgba32f storage image, binding 0), the output is
@@ -157,6 +161,20 @@ int rt_render_frames(rt_handle h, uint32_t first_frame, uint32_t n_frames, void 
 int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
                     uint32_t row_begin, uint32_t row_end, int write_output, void *stream);
 
+/* rt_render_shard with interleaved rows, for load balance across GPUs (the sky
+ * rows of an image are cheaper than its ground rows): the image is cut into
+ * stripes of stripe_rows rows, stripe k = rows [k * stripe_rows,
+ * min(height, (k + 1) * stripe_rows)), and the call renders stripes
+ * stripe_first, stripe_first + stripe_stride, ... to the bottom of the image
+ * (rank r of G passes stripe_first = r, stripe_stride = G).  Pixel coordinates
+ * stay global (raytrace.comp.glsl:310-311), so the stripes of all ranks put
+ * together are the unsharded image bit for bit.  Clear rule as for
+ * rt_render_shard, with "the rows this call renders".  No counterpart in the
+ * reference (one device, src/vk/VulkanContext.cpp:413-414). */
+int rt_render_stripes(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                      uint32_t stripe_rows, uint32_t stripe_first, uint32_t stripe_stride, int write_output,
+                      void *stream);
+
 /* The display tail of the shader alone, raytrace.comp.glsl:337-342: divides the
  * accumulator by float(sample_count), applies c/(c+1) and pow(max(c,0),1/2.2),
  * stores rgba8 for rows [row_begin,row_end).  sample_count is the shader's
@@ -183,6 +201,11 @@ int rt_read_output(rt_handle h, uint8_t *host, size_t bytes, void *stream);
  * stream of raytrace.comp.glsl:310-331 can be compared word for word. */
 int rt_enable_rng_capture(rt_handle h, int enable);
 int rt_read_rng_state(rt_handle h, uint32_t *host, size_t bytes, void *stream);
+
+/* Test hook: the nth device allocation the library makes from now on (1 = the
+ * next one) fails with an out-of-memory error; 0 switches the hook off.  Lets
+ * tests reach the error paths of rt_resize / rt_set_spheres / rt_render_frames. */
+void rt_debug_fail_allocation(int nth);
 
 /* Waits for `stream` (vkDeviceWaitIdle in the reference's resize/destroy). */
 int rt_synchronize(rt_handle h, void *stream);

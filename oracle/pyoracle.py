@@ -87,6 +87,8 @@ def lib():
         L.rto_render.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Sphere), ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
                                  ctypes.POINTER(Counters)]
+        L.rto_resolve.restype = None
+        L.rto_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         L.rto_hit_sphere.restype = ctypes.c_int
         L.rto_hit_sphere.argtypes = [ctypes.POINTER(Sphere), f32p, f32p, ctypes.c_float, ctypes.c_float,
                                      f32p, f32p, f32p, ctypes.POINTER(ctypes.c_int)]
@@ -198,6 +200,15 @@ def render(params, spheres, accum=None, want_output=True, want_rng=False, y0=0, 
                           ctypes.byref(cnt) if cnt is not None else None)
     assert rc == 0
     return {"accum": accum, "output": out, "rng": rng, "counters": cnt.as_dict() if cnt else None}
+
+
+def resolve(accum, sample_count):
+    """The display tail alone (raytrace.comp.glsl:337-342): accum (..., 4) float32 -> (..., 4) uint8."""
+    a = np.ascontiguousarray(accum, dtype=np.float32)
+    assert a.shape[-1] == 4
+    out = np.zeros(a.shape, dtype=np.uint8)
+    lib().rto_resolve(a.ctypes.data, out.ctypes.data, a.size // 4, int(sample_count) & 0xFFFFFFFF)
+    return out
 
 
 def hit_sphere(sphere12, o, d, tmin, tmax):

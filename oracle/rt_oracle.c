@@ -516,6 +516,28 @@ static inline uint8_t unorm8(float c)
     return (uint8_t)floorf(x * 255.0f + 0.5f);
 }
 
+/* The display tail, raytrace.comp.glsl:337-342, for one texel: total / sample_count, c / (c + 1),
+ * pow(max(c, 0), 1/2.2), UNORM8 store. */
+static void display_tail(v3 total, float sample_count, uint8_t *out4)
+{
+    v3 color = divs(total, sample_count);
+    color = V(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));
+    /* vec3(1.0 / 2.2): the GLSL front end folds the constant in double */
+    const float inv_gamma = (float)(1.0 / 2.2);
+    out4[0] = unorm8(rto_powf(glsl_max(color.x, 0.0f), inv_gamma));
+    out4[1] = unorm8(rto_powf(glsl_max(color.y, 0.0f), inv_gamma));
+    out4[2] = unorm8(rto_powf(glsl_max(color.z, 0.0f), inv_gamma));
+    out4[3] = 255;
+}
+
+void rto_resolve(const float *accum, uint8_t *out_rgba8, size_t texels, uint32_t sample_count)
+{
+    size_t i;
+    for (i = 0; i < texels; ++i) {
+        display_tail(V(accum[4 * i], accum[4 * i + 1], accum[4 * i + 2]), (float)sample_count, out_rgba8 + 4 * i);
+    }
+}
+
 /* raytrace.comp.glsl:298-343 for one pixel */
 static void shade_pixel(const rto_params *pr, const rto_sphere *spheres, uint32_t px, uint32_t py,
                         uint32_t width, float *accum, uint8_t *out8, uint32_t *rng_final, rto_counters *c)
@@ -545,15 +567,7 @@ static void shade_pixel(const rto_params *pr, const rto_sphere *spheres, uint32_
     }
     if (out8) {
         /* (frame + 1u) * spp wraps in uint32 before the conversion */
-        float sample_count = (float)((frame + 1u) * spp_raw);
-        v3 color = divs(total, sample_count);
-        color = V(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));
-        /* vec3(1.0 / 2.2): the GLSL front end folds the constant in double */
-        const float inv_gamma = (float)(1.0 / 2.2);
-        out8[idx * 4 + 0] = unorm8(rto_powf(glsl_max(color.x, 0.0f), inv_gamma));
-        out8[idx * 4 + 1] = unorm8(rto_powf(glsl_max(color.y, 0.0f), inv_gamma));
-        out8[idx * 4 + 2] = unorm8(rto_powf(glsl_max(color.z, 0.0f), inv_gamma));
-        out8[idx * 4 + 3] = 255;
+        display_tail(total, (float)((frame + 1u) * spp_raw), out8 + idx * 4);
     }
 }
 

@@ -35,6 +35,7 @@
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -131,6 +132,10 @@ void rto_default_aim(const float pos[3], float dir_out[3], float *focus_out);
 int rto_render(const rto_params *params, const rto_sphere *spheres,
                float *accum, uint8_t *out_rgba8, uint32_t *rng_final,
                uint32_t y0, uint32_t y1, int nthreads, rto_counters *counters);
+
+/* The display tail of the shader alone (raytrace.comp.glsl:337-342) over `texels` float4 texels:
+ * sample_count is the shader's (frame + 1) * spp, already wrapped to 32 bits. */
+void rto_resolve(const float *accum, uint8_t *out_rgba8, size_t texels, uint32_t sample_count);
 
 /* Per-function probes for vector tests (exact float comparison with HIP). */
 /* in: ray o[3], d[3], sphere; out: returns hit flag, fills t,p,n,front */

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +102,18 @@ int fail_arg(rt_tracer* h, const char* what)
         g_create_error = std::string("bad argument: ") + what;
     }
     return RT_ERR_BAD_ARGUMENT;
+}
+
+// Test hook (rt_debug_fail_allocation): the n-th device allocation from now on reports
+// hipErrorOutOfMemory, so that the error paths of resize / scene changes can be exercised.
+std::atomic<int> g_fail_allocation_in{ 0 };
+hipError_t device_malloc(void** ptr, size_t bytes)
+{
+    if (g_fail_allocation_in.load() > 0 && g_fail_allocation_in.fetch_sub(1) == 1) {
+        *ptr = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(ptr, bytes);
 }
 
 #define RT_HIP_TRY(h, expr)                                              \
@@ -231,6 +244,19 @@ void update_params(const rt_tracer& t, uint32_t frame_index, rt_gpu_params& para
     params.frame_sample_depth_count[3] = static_cast<uint32_t>(t.spheres.size());
 }
 
+// The device images of one extent.
+struct Images {
+    float4* accum = nullptr;
+    uint32_t* output = nullptr;
+    uint32_t* rng_state = nullptr;
+    void release()
+    {
+        if (accum) { (void)hipFree(accum); accum = nullptr; }
+        if (output) { (void)hipFree(output); output = nullptr; }
+        if (rng_state) { (void)hipFree(rng_state); rng_state = nullptr; }
+    }
+};
+
 void free_images(rt_tracer* h)
 {
     if (h->accum) { (void)hipFree(h->accum); h->accum = nullptr; }
@@ -240,120 +266,198 @@ void free_images(rt_tracer* h)
 }
 
 // RayTracer::createAccumulationImage, src/rt/RayTracer.cpp:498-527 (+ the output image
-// that the reference borrows from the swapchain)
-int allocate_images(rt_tracer* h)
+// that the reference borrows from the swapchain).  Allocates into `out`; the handle is
+// not touched, so a failure leaves it as it was.
+int allocate_images(rt_tracer* h, uint32_t width, uint32_t height, Images& out)
 {
-    const size_t pixels = static_cast<size_t>(h->width) * h->height;
-    RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->accum), pixels * sizeof(float4)));
-    RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->output), pixels * sizeof(uint32_t)));
-    RT_HIP_TRY(h, hipMemset(h->output, 0, pixels * sizeof(uint32_t)));
-    if (h->rng_capture) {
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->rng_state), pixels * sizeof(uint32_t)));
+    const size_t pixels = static_cast<size_t>(width) * height;
+    auto body = [&]() -> int {
+        RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.accum), pixels * sizeof(float4)));
+        RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.output), pixels * sizeof(uint32_t)));
+        RT_HIP_TRY(h, hipMemset(out.output, 0, pixels * sizeof(uint32_t)));
+        if (h->rng_capture) {
+            RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.rng_state), pixels * sizeof(uint32_t)));
+            RT_HIP_TRY(h, hipMemset(out.rng_state, 0, pixels * sizeof(uint32_t)));
+        }
+        return RT_OK;
+    };
+    const int rc = body();
+    if (rc != RT_OK) {
+        out.release();
     }
-    return RT_OK;
+    return rc;
 }
 
-// Hierarchy and range flag of the current sphere list (host side of a scene change).
-void index_scene(rt_tracer* h)
+// What a sphere list needs besides its records: the range flag and the hierarchy.
+struct SceneIndex {
+    bool bounded = true;
+    rt::SphereTree tree;
+};
+
+void index_scene(const std::vector<rt_gpu_sphere>& spheres, SceneIndex& out)
 {
-    h->scene_bounded = true;
-    for (const rt_gpu_sphere& s : h->spheres) {
+    out.bounded = true;
+    for (const rt_gpu_sphere& s : spheres) {
         for (int k = 0; k < 4; ++k) {
             if (!(std::fabs(s.center_radius[k]) <= 0x1p20f)) { // also catches NaN
-                h->scene_bounded = false;
+                out.bounded = false;
             }
         }
     }
-    (void)rt::build_sphere_tree(h->spheres.data(), static_cast<uint32_t>(h->spheres.size()), h->tree); // empty when the scene does not qualify
+    (void)rt::build_sphere_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.tree); // empty when the scene does not qualify
 }
 
-// RayTracer::uploadScene, src/rt/RayTracer.cpp:529-548
-int upload_scene(rt_tracer* h, hipStream_t stream)
-{
-    const uint32_t n = static_cast<uint32_t>(h->spheres.size());
-    // the previous scene may still be read by a kernel in flight
-    RT_HIP_TRY(h, hipDeviceSynchronize());
-    if (n > h->d_sphere_capacity) {
-        if (h->d_spheres) {
-            (void)hipFree(h->d_spheres);
-            h->d_spheres = nullptr;
-            h->d_sphere_capacity = 0;
+// A device buffer that is either the handle's current one (large enough) or a fresh allocation
+// that replaces it once the whole scene change has succeeded.
+struct Staged {
+    void* ptr = nullptr;
+    bool fresh = false;
+    hipError_t take(void* current, size_t current_capacity, size_t need, size_t bytes)
+    {
+        if (current != nullptr && need <= current_capacity) {
+            ptr = current;
+            return hipSuccess;
         }
-        RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_spheres), n * sizeof(rt_gpu_sphere)));
-        h->d_sphere_capacity = n;
+        fresh = true;
+        return device_malloc(&ptr, bytes);
     }
+    void drop() { if (fresh && ptr) { (void)hipFree(ptr); } ptr = nullptr; fresh = false; }
+};
+
+// RayTracer::uploadScene, src/rt/RayTracer.cpp:529-548, for a new sphere list: every device buffer the
+// scene needs is allocated (where the current one is too small) and filled BEFORE the handle changes,
+// so a failure half way leaves the previous scene, its hierarchy and its device copies intact.
+int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
+{
+    SceneIndex index;
+    index_scene(spheres, index);
+    if (h->device < 0) {
+        h->spheres = std::move(spheres);
+        h->tree = std::move(index.tree);
+        h->scene_bounded = index.bounded;
+        return RT_OK;
+    }
+    const uint32_t n = static_cast<uint32_t>(spheres.size());
     // The node arrays hold one entry more than the tree has nodes: the walk fetches the node behind
     // the one it is testing, also behind the last.  Words: one per node (packed) or two (wide).
-    const uint32_t nodes = h->tree.node_count();
+    const uint32_t nodes = index.tree.node_count();
+    std::vector<float> tree_geom;
+    std::vector<uint32_t> tree_words;
     if (nodes != 0) {
-        std::vector<float> geom(h->tree.geom);
-        geom.resize((static_cast<size_t>(nodes) + 1u) * 4u, 0.0f);
-        std::vector<uint32_t> words;
-        if (h->tree.packed()) {
-            words = h->tree.word;
-            words.push_back(0u);
+        tree_geom = index.tree.geom;
+        tree_geom.resize((static_cast<size_t>(nodes) + 1u) * 4u, 0.0f);
+        if (index.tree.packed()) {
+            tree_words = index.tree.word;
+            tree_words.push_back(0u);
             // the LDS walk reads an inner node's continuation from its fourth float: sign bit set, the
             // value rounded up to a multiple of 2^13 ulps, the node index in the 13 bits that frees
             for (uint32_t i = 0; i < nodes; ++i) {
-                if (h->tree.sphere[i] == rt::kTreeNoSphere) {
+                if (index.tree.sphere[i] == rt::kTreeNoSphere) {
                     uint32_t bits;
-                    std::memcpy(&bits, &geom[4u * i + 3u], sizeof bits);
-                    bits = ((bits + 0x1FFFu) & ~0x1FFFu) | h->tree.link[i] | 0x80000000u;
-                    std::memcpy(&geom[4u * i + 3u], &bits, sizeof bits);
+                    std::memcpy(&bits, &tree_geom[4u * i + 3u], sizeof bits);
+                    bits = ((bits + 0x1FFFu) & ~0x1FFFu) | index.tree.link[i] | 0x80000000u;
+                    std::memcpy(&tree_geom[4u * i + 3u], &bits, sizeof bits);
                 }
             }
         } else {
-            words.resize((static_cast<size_t>(nodes) + 1u) * 2u, 0u);
+            tree_words.resize((static_cast<size_t>(nodes) + 1u) * 2u, 0u);
             for (uint32_t i = 0; i < nodes; ++i) {
-                words[2u * i] = h->tree.link[i] * 16u;
-                words[2u * i + 1u] = h->tree.sphere[i] == rt::kTreeNoSphere ? 0u : rt::kTreeLeafFlag | h->tree.sphere[i];
+                tree_words[2u * i] = index.tree.link[i] * 16u;
+                tree_words[2u * i + 1u] = index.tree.sphere[i] == rt::kTreeNoSphere ? 0u : rt::kTreeLeafFlag | index.tree.sphere[i];
             }
         }
-        if (nodes > h->d_tree_capacity) {
-            RT_HIP_TRY(h, hipDeviceSynchronize());
-            if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); h->d_tree_geom = nullptr; }
-            if (h->d_tree_word) { (void)hipFree(h->d_tree_word); h->d_tree_word = nullptr; }
-            h->d_tree_capacity = 0;
-            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_geom), (static_cast<size_t>(nodes) + 1u) * sizeof(float4)));
-            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tree_word), (static_cast<size_t>(nodes) + 1u) * 2u * sizeof(uint32_t)));
-            h->d_tree_capacity = nodes;
-        }
-        if (h->d_unit_counter == nullptr) {
-            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_unit_counter), 256));
-        }
-        RT_HIP_TRY(h, hipMemcpy(h->d_tree_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
-        RT_HIP_TRY(h, hipMemcpy(h->d_tree_word, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    std::vector<float> loop_geom;
     if (n > rt::kMaxSpheresGeomLds) {
         // (centre, radius^2) records for the loop over all spheres in global memory
-        std::vector<float> geom(static_cast<size_t>(n) * 4u);
+        loop_geom.resize(static_cast<size_t>(n) * 4u);
         for (uint32_t i = 0; i < n; ++i) {
-            const float* cr = h->spheres[i].center_radius;
-            geom[4u * i + 0u] = cr[0];
-            geom[4u * i + 1u] = cr[1];
-            geom[4u * i + 2u] = cr[2];
-            geom[4u * i + 3u] = cr[3] * cr[3];
+            const float* cr = spheres[i].center_radius;
+            loop_geom[4u * i + 0u] = cr[0];
+            loop_geom[4u * i + 1u] = cr[1];
+            loop_geom[4u * i + 2u] = cr[2];
+            loop_geom[4u * i + 3u] = cr[3] * cr[3];
         }
-        if (n > h->d_loop_geom_capacity) {
-            RT_HIP_TRY(h, hipDeviceSynchronize());
-            if (h->d_loop_geom) { (void)hipFree(h->d_loop_geom); h->d_loop_geom = nullptr; }
-            h->d_loop_geom_capacity = 0;
-            RT_HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_loop_geom), static_cast<size_t>(n) * sizeof(float4)));
-            h->d_loop_geom_capacity = n;
-        }
-        RT_HIP_TRY(h, hipMemcpy(h->d_loop_geom, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    // pageable-memory copy: returns once the source has been staged, ordered on the stream
-    RT_HIP_TRY(h, hipMemcpyAsync(h->d_spheres, h->spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice, stream));
-    RT_HIP_TRY(h, hipStreamSynchronize(stream));
+
+    // the previous scene may still be read by a kernel in flight, on whatever stream (vkDeviceWaitIdle
+    // in the reference's resize/destroy; scene changes are rare)
+    RT_HIP_TRY(h, hipDeviceSynchronize());
+    Staged d_spheres, d_tree_geom, d_tree_word, d_loop_geom, d_counter;
+    auto body = [&]() -> int {
+        RT_HIP_TRY(h, d_spheres.take(h->d_spheres, h->d_sphere_capacity, n, n * sizeof(rt_gpu_sphere)));
+        if (nodes != 0) {
+            RT_HIP_TRY(h, d_tree_geom.take(h->d_tree_geom, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * sizeof(float4)));
+            RT_HIP_TRY(h, d_tree_word.take(h->d_tree_word, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * 2u * sizeof(uint32_t)));
+            RT_HIP_TRY(h, d_counter.take(h->d_unit_counter, 1, 1, 256));
+        }
+        if (!loop_geom.empty()) {
+            RT_HIP_TRY(h, d_loop_geom.take(h->d_loop_geom, h->d_loop_geom_capacity, n, static_cast<size_t>(n) * sizeof(float4)));
+        }
+        return RT_OK;
+    };
+    int rc = body();
+    if (rc == RT_OK) {
+        // From here on buffers the handle already owns may be overwritten; if one of these blocking copies
+        // fails the device copy of the scene is unusable, and the handle says so (render refuses to launch).
+        auto copies = [&]() -> int {
+            RT_HIP_TRY(h, hipMemcpy(d_spheres.ptr, spheres.data(), n * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice));
+            if (nodes != 0) {
+                RT_HIP_TRY(h, hipMemcpy(d_tree_geom.ptr, tree_geom.data(), tree_geom.size() * sizeof(float), hipMemcpyHostToDevice));
+                RT_HIP_TRY(h, hipMemcpy(d_tree_word.ptr, tree_words.data(), tree_words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+            if (!loop_geom.empty()) {
+                RT_HIP_TRY(h, hipMemcpy(d_loop_geom.ptr, loop_geom.data(), loop_geom.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            return RT_OK;
+        };
+        rc = copies();
+        if (rc != RT_OK && !d_spheres.fresh && h->d_spheres != nullptr) {
+            (void)hipFree(h->d_spheres);
+            h->d_spheres = nullptr;
+            h->d_sphere_capacity = 0;
+            d_spheres.ptr = nullptr;
+        }
+    }
+    if (rc != RT_OK) {
+        d_spheres.drop();
+        d_tree_geom.drop();
+        d_tree_word.drop();
+        d_loop_geom.drop();
+        d_counter.drop();
+        return rc;
+    }
+    // commit
+    if (d_spheres.fresh) {
+        if (h->d_spheres) { (void)hipFree(h->d_spheres); }
+        h->d_spheres = static_cast<rt_gpu_sphere*>(d_spheres.ptr);
+        h->d_sphere_capacity = n;
+    }
+    if (d_tree_geom.fresh || d_tree_word.fresh) {
+        // the two arrays share one capacity figure: both were (re)allocated together above
+        if (h->d_tree_geom && d_tree_geom.fresh) { (void)hipFree(h->d_tree_geom); }
+        if (h->d_tree_word && d_tree_word.fresh) { (void)hipFree(h->d_tree_word); }
+        h->d_tree_geom = static_cast<float4*>(d_tree_geom.ptr);
+        h->d_tree_word = static_cast<uint32_t*>(d_tree_word.ptr);
+        h->d_tree_capacity = nodes;
+    }
+    if (d_counter.fresh) {
+        h->d_unit_counter = static_cast<uint32_t*>(d_counter.ptr);
+    }
+    if (d_loop_geom.fresh) {
+        if (h->d_loop_geom) { (void)hipFree(h->d_loop_geom); }
+        h->d_loop_geom = static_cast<float4*>(d_loop_geom.ptr);
+        h->d_loop_geom_capacity = n;
+    }
+    h->spheres = std::move(spheres);
+    h->tree = std::move(index.tree);
+    h->scene_bounded = index.bounded;
     return RT_OK;
 }
 
 // RayTracer::create, src/rt/RayTracer.cpp:188-193: default scene and the create-time aim
 void init_default_state(rt_tracer* h)
 {
-    build_default_scene(h->spheres);
-    index_scene(h);
     const V3 look_at = v3(0.0f, 1.0f, 0.0f);
     const V3 pos = v3(h->cam_pos[0], h->cam_pos[1], h->cam_pos[2]);
     const V3 d = look_at - pos;
@@ -381,11 +485,44 @@ bool valid_extent(uint32_t w, uint32_t hgt)
     return w >= 1 && hgt >= 1 && w <= 65536u && hgt <= 65536u && static_cast<uint64_t>(w) * hgt < (1ull << 32);
 }
 
-int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
-                uint32_t row_begin, uint32_t row_end, bool write_output, hipStream_t stream)
+// Clears the rows of `rows` in the accumulator (vkCmdClearColorImage of :595-600, restricted to a shard).
+int clear_rows(rt_tracer* h, const rt::RowSet& rows, hipStream_t stream)
 {
-    if (row_begin > row_end || row_end > h->height) {
-        return fail_arg(h, "row range outside the image");
+    const size_t row_bytes = static_cast<size_t>(h->width) * sizeof(float4);
+    if (rows.stripe_rows == 0) {
+        if (rows.row_end > rows.row_begin) {
+            RT_HIP_TRY(h, hipMemsetAsync(h->accum + static_cast<size_t>(rows.row_begin) * h->width, 0,
+                                         static_cast<size_t>(rows.row_end - rows.row_begin) * row_bytes, stream));
+        }
+        return RT_OK;
+    }
+    for (uint32_t k = 0; k < rows.n_stripes; ++k) {
+        const uint64_t top = (static_cast<uint64_t>(rows.stripe_first) + static_cast<uint64_t>(k) * rows.stripe_stride) * rows.stripe_rows;
+        if (top >= h->height) {
+            break;
+        }
+        const uint64_t bottom = std::min<uint64_t>(top + rows.stripe_rows, h->height);
+        RT_HIP_TRY(h, hipMemsetAsync(h->accum + top * h->width, 0, (bottom - top) * row_bytes, stream));
+    }
+    return RT_OK;
+}
+
+int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                const rt::RowSet& rows, bool write_output, hipStream_t stream)
+{
+    if (rows.stripe_rows == 0) {
+        if (rows.row_begin > rows.row_end || rows.row_end > h->height) {
+            return fail_arg(h, "row range outside the image");
+        }
+    } else {
+        const uint64_t stripes_in_image = (static_cast<uint64_t>(h->height) + rows.stripe_rows - 1) / rows.stripe_rows;
+        if (rows.stripe_stride == 0) {
+            return fail_arg(h, "stripe_stride must be >= 1");
+        }
+        if (rows.n_stripes != 0 &&
+            static_cast<uint64_t>(rows.stripe_first) + static_cast<uint64_t>(rows.n_stripes - 1) * rows.stripe_stride >= stripes_in_image) {
+            return fail_arg(h, "stripe range outside the image");
+        }
     }
     RT_NEED_DEVICE(h);
     if (n_frames == 0) {
@@ -394,30 +531,27 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     if (frame_stride == 0) {
         return fail_arg(h, "frame_stride must be >= 1");
     }
+    if (h->accum == nullptr || h->output == nullptr || h->d_spheres == nullptr) {
+        // an earlier rt_resize / rt_set_spheres ran out of memory half way
+        h->error = "the handle has no images or no scene on the device (an earlier resize or scene upload failed)";
+        return RT_ERR_HIP;
+    }
     DeviceScope scope(h->device);
     RT_HIP_TRY(h, scope.status());
 
-    // RayTracer::render, src/rt/RayTracer.cpp:564-603.  A raised flag clears the whole image once;
-    // frame 0 clears the rows this call renders (the whole image for an unsharded call), so row
-    // bands rendered one after another on one handle do not wipe each other.
-    if (h->reset_accum) {
-        const size_t bytes = static_cast<size_t>(h->width) * h->height * sizeof(float4);
-        RT_HIP_TRY(h, hipMemsetAsync(h->accum, 0, bytes, stream));
-        h->reset_accum = false;
-    } else if (first_frame == 0 && row_end > row_begin) {
-        const size_t offset = static_cast<size_t>(row_begin) * h->width;
-        const size_t bytes = static_cast<size_t>(row_end - row_begin) * h->width * sizeof(float4);
-        RT_HIP_TRY(h, hipMemsetAsync(h->accum + offset, 0, bytes, stream));
-    }
+    const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
+    const size_t frame_bytes = image_pixels * sizeof(float4);
+    const bool tree = h->use_tree && !h->tree.empty();
 
+    // Workspace of this call: per-frame sums (launches of several frames) and the unit counter (hierarchy).
+    float4* partial = h->partial;
+    uint32_t* unit_counter = h->d_unit_counter;
+    uint32_t group = n_frames;
     // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
     // accumulator in frame order afterwards; the frames of one call are split into groups so that
     // this image stays within a budget: 16 GiB (a 64-frame batch at 3840x2160 is 8.5 GB and should
     // stay one launch on a 288 GB device), at most a quarter of the memory that is free when the
     // buffer has to grow, or what RT_PARTIAL_BYTES says.
-    const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
-    const size_t frame_bytes = image_pixels * sizeof(float4);
-    uint32_t group = n_frames;
     if (n_frames > 1) {
         size_t budget = static_cast<size_t>(16) << 30;
         if (const char* e = std::getenv("RT_PARTIAL_BYTES")) {
@@ -434,7 +568,8 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         const size_t fit = std::max<size_t>(2, budget / frame_bytes);
         group = static_cast<uint32_t>(std::min<size_t>(n_frames, fit));
         if (static_cast<size_t>(group) * frame_bytes > h->partial_bytes) {
-            RT_HIP_TRY(h, hipStreamSynchronize(stream));
+            // kernels of earlier calls may still be reading the old buffer, whatever stream they are on
+            RT_HIP_TRY(h, hipDeviceSynchronize());
             if (h->partial) {
                 (void)hipFree(h->partial);
                 h->partial = nullptr;
@@ -443,7 +578,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             // an allocation that does not fit is retried with half the frames, down to two
             for (;;) {
                 const size_t need = static_cast<size_t>(group) * frame_bytes;
-                const hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->partial), need);
+                const hipError_t e = device_malloc(reinterpret_cast<void**>(&h->partial), need);
                 if (e == hipSuccess) {
                     h->partial_bytes = need;
                     break;
@@ -456,7 +591,21 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
                 group = std::max(2u, group / 2u);
             }
         }
+        partial = h->partial;
     }
+    // RayTracer::render, src/rt/RayTracer.cpp:564-603.  A raised flag clears the whole image once;
+    // frame 0 clears the rows this call renders (the whole image for an unsharded call), so row
+    // bands rendered one after another on one handle do not wipe each other.
+    if (h->reset_accum) {
+        RT_HIP_TRY(h, hipMemsetAsync(h->accum, 0, frame_bytes, stream));
+        h->reset_accum = false;
+    } else if (first_frame == 0) {
+        const int rc = clear_rows(h, rows, stream);
+        if (rc != RT_OK) {
+            return rc;
+        }
+    }
+
     // Unit geometry (frames pooled per unit, pixel tile): defaults are chosen by launch_trace;
     // RT_FRAMES_PER_UNIT and RT_TILE_LOG2="w h" override them for experiments.
     uint32_t frames_per_unit = 64;
@@ -482,20 +631,23 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.output = (write_output && count == 1) ? h->output : nullptr;
         args.spheres = h->d_spheres;
         args.rng_out = (h->rng_capture && last_group) ? h->rng_state : nullptr;
-        args.partial = count > 1 ? h->partial : nullptr;
+        args.partial = count > 1 ? partial : nullptr;
         args.stats = h->stats;
-        const bool tree = h->use_tree && !h->tree.empty();
         args.tree_geom = tree ? h->d_tree_geom : nullptr;
         args.tree_word = tree ? h->d_tree_word : nullptr;
-        args.unit_counter = tree ? h->d_unit_counter : nullptr;
+        args.unit_counter = tree ? unit_counter : nullptr;
         args.tree_nodes = tree ? h->tree.node_count() : 0u;
         args.tree_packed = tree && h->tree.packed() ? 1u : 0u;
         args.loop_geom = h->d_loop_geom;
         args.scene_bounded = h->scene_bounded ? 1u : 0u;
         args.width = h->width;
         args.height = h->height;
-        args.row_begin = row_begin;
-        args.row_end = row_end;
+        args.row_begin = rows.row_begin;
+        args.row_end = rows.row_end;
+        args.stripe_rows = rows.stripe_rows;
+        args.stripe_first = rows.stripe_first;
+        args.stripe_stride = rows.stripe_stride;
+        args.n_stripes = rows.n_stripes;
         args.first_frame = first;
         args.n_frames = count;
         args.frame_stride = frame_stride;
@@ -512,19 +664,21 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
 
         if (count > 1) {
             const uint32_t last_frame = first + (count - 1) * frame_stride;
-            const size_t first_texel = static_cast<size_t>(row_begin) * h->width;
-            const size_t texels = static_cast<size_t>(row_end - row_begin) * h->width;
-            if (texels > 0xFFFFFFFFull) {
-                return fail_arg(h, "image too large for the fold kernel");
-            }
             // (frame + 1u) * spp wraps in uint32 before the conversion, raytrace.comp.glsl:337
             const float sample_count = static_cast<float>((last_frame + 1u) * h->samples_per_pixel);
-            RT_HIP_TRY(h, rt::launch_fold(h->accum, h->partial, (write_output && last_group) ? h->output : nullptr,
-                                          image_pixels, first_texel, static_cast<uint32_t>(texels), count, sample_count,
-                                          stream));
+            RT_HIP_TRY(h, rt::launch_fold(h->accum, partial, (write_output && last_group) ? h->output : nullptr,
+                                          h->width, h->height, rows, count, sample_count, stream));
         }
     }
     return RT_OK;
+}
+
+rt::RowSet band(uint32_t row_begin, uint32_t row_end)
+{
+    rt::RowSet rows;
+    rows.row_begin = row_begin;
+    rows.row_end = row_end;
+    return rows;
 }
 
 } // namespace
@@ -562,8 +716,11 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
     h->height = height;
     h->reset_accum = true;
     init_default_state(h);
+    std::vector<rt_gpu_sphere> scene;
+    build_default_scene(scene);
     if (device_id == RT_DEVICE_NONE) {
         // host-state-only handle: setters, rt_get_params and rt_get_spheres work, nothing renders
+        (void)install_scene(h, std::move(scene));
         *out = h;
         return RT_OK;
     }
@@ -577,11 +734,19 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_start[i]));
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_stop[i]));
             }
-            int r = upload_scene(h, nullptr);
+            int r = install_scene(h, std::move(scene));
             if (r != RT_OK) {
                 return r;
             }
-            return allocate_images(h);
+            Images images;
+            r = allocate_images(h, width, height, images);
+            if (r != RT_OK) {
+                return r;
+            }
+            h->accum = images.accum;
+            h->output = images.output;
+            h->rng_state = images.rng_state;
+            return RT_OK;
         };
         rc = body();
     }
@@ -610,12 +775,25 @@ int rt_resize(rt_handle h, uint32_t width, uint32_t height)
     }
     DeviceScope scope(h->device);
     RT_HIP_TRY(h, scope.status());
-    RT_HIP_TRY(h, hipDeviceSynchronize()); // vkDeviceWaitIdle, :203
-    free_images(h);
+    // the new images first: if they do not fit, the handle keeps its old extent and images
+    Images images;
+    const int rc = allocate_images(h, width, height, images);
+    if (rc != RT_OK) {
+        return rc;
+    }
+    const hipError_t idle = hipDeviceSynchronize(); // vkDeviceWaitIdle, :203
+    if (idle != hipSuccess) {
+        images.release();
+        return fail_hip(h, idle, "hipDeviceSynchronize()", __FILE__, __LINE__);
+    }
+    free_images(h); // also the per-frame sums, whose size follows the extent
+    h->accum = images.accum;
+    h->output = images.output;
+    h->rng_state = images.rng_state;
     h->width = width;
     h->height = height;
     h->reset_accum = true; // :228
-    return allocate_images(h);
+    return RT_OK;
 }
 
 int rt_destroy(rt_handle h)
@@ -720,15 +898,19 @@ int rt_set_spheres(rt_handle h, const rt_gpu_sphere* spheres, uint32_t n)
     if (n > rt::kMaxSpheres) {
         return fail_arg(h, "more than 1048576 spheres");
     }
-    h->spheres.assign(spheres, spheres + n);
-    index_scene(h);
-    h->reset_accum = true;
+    std::vector<rt_gpu_sphere> scene(spheres, spheres + n);
+    int rc;
     if (h->device < 0) {
-        return RT_OK;
+        rc = install_scene(h, std::move(scene));
+    } else {
+        DeviceScope scope(h->device);
+        RT_HIP_TRY(h, scope.status());
+        rc = install_scene(h, std::move(scene));
     }
-    DeviceScope scope(h->device);
-    RT_HIP_TRY(h, scope.status());
-    return upload_scene(h, nullptr);
+    if (rc == RT_OK) {
+        h->reset_accum = true;
+    }
+    return rc;
 }
 
 int rt_get_spheres(rt_handle h, rt_gpu_sphere* out, uint32_t cap, uint32_t* n)
@@ -822,7 +1004,7 @@ int rt_render(rt_handle h, uint32_t frame_index, void* stream)
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
     }
-    return render_impl(h, frame_index, 1, 1, 0, h->height, true, static_cast<hipStream_t>(stream));
+    return render_impl(h, frame_index, 1, 1, band(0, h->height), true, static_cast<hipStream_t>(stream));
 }
 
 int rt_render_frames(rt_handle h, uint32_t first_frame, uint32_t n_frames, void* stream)
@@ -830,7 +1012,7 @@ int rt_render_frames(rt_handle h, uint32_t first_frame, uint32_t n_frames, void*
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
     }
-    return render_impl(h, first_frame, n_frames, 1, 0, h->height, true, static_cast<hipStream_t>(stream));
+    return render_impl(h, first_frame, n_frames, 1, band(0, h->height), true, static_cast<hipStream_t>(stream));
 }
 
 int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
@@ -839,8 +1021,31 @@ int rt_render_shard(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
     }
-    return render_impl(h, first_frame, n_frames, frame_stride, row_begin, row_end, write_output != 0,
+    return render_impl(h, first_frame, n_frames, frame_stride, band(row_begin, row_end), write_output != 0,
                        static_cast<hipStream_t>(stream));
+}
+
+int rt_render_stripes(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
+                      uint32_t stripe_rows, uint32_t stripe_first, uint32_t stripe_stride, int write_output, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    if (stripe_rows == 0 || stripe_stride == 0) {
+        return fail_arg(h, "stripe_rows and stripe_stride must be >= 1");
+    }
+    rt::RowSet rows;
+    rows.stripe_rows = stripe_rows;
+    rows.stripe_first = stripe_first;
+    rows.stripe_stride = stripe_stride;
+    const uint64_t stripes_in_image = (static_cast<uint64_t>(h->height) + stripe_rows - 1) / stripe_rows;
+    rows.n_stripes = stripe_first < stripes_in_image
+                         ? static_cast<uint32_t>((stripes_in_image - stripe_first + stripe_stride - 1) / stripe_stride)
+                         : 0u;
+    if (rows.n_stripes == 0) {
+        return RT_OK; // more shards than stripes: nothing to render for this one
+    }
+    return render_impl(h, first_frame, n_frames, frame_stride, rows, write_output != 0, static_cast<hipStream_t>(stream));
 }
 
 namespace {
@@ -1041,6 +1246,11 @@ int rt_debug_read_stats(rt_handle h, unsigned long long* out, int reset)
     return RT_OK;
 }
 #endif
+
+void rt_debug_fail_allocation(int nth)
+{
+    g_fail_allocation_in.store(nth > 0 ? nth : 0);
+}
 
 const char* rt_last_error(rt_handle h)
 {

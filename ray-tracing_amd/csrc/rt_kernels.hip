@@ -453,9 +453,20 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
     const uint32_t tile_x = tile - tile_y * A->tiles_x;
     // the pixel tile of a unit is 2^tile_w_log2 x 2^tile_h_log2, at most 8 x 8
     u.x0 = tile_x << A->tile_w_log2;
-    u.y0 = A->row_begin + (tile_y << A->tile_h_log2);
     u.tile_w = min(1u << A->tile_w_log2, A->width - u.x0);
-    u.tile_h = min(1u << A->tile_h_log2, A->row_end - u.y0);
+    const uint32_t rel_row = tile_y << A->tile_h_log2;
+    if (A->stripe_rows == 0u) {
+        u.y0 = A->row_begin + rel_row;
+        u.tile_h = min(1u << A->tile_h_log2, A->row_end - u.y0);
+    } else {
+        // interleaved stripes: the launch's rows are numbered through its own stripes (the host keeps
+        // the tile height a divisor of stripe_rows, so a tile never straddles two stripes)
+        const uint32_t k = rel_row / A->stripe_rows;
+        const uint32_t top = (A->stripe_first + k * A->stripe_stride) * A->stripe_rows;
+        u.y0 = top + (rel_row - k * A->stripe_rows);
+        const uint32_t bottom = min(top + A->stripe_rows, A->height); // the last stripe of the image may be cut short
+        u.tile_h = u.y0 < bottom ? min(1u << A->tile_h_log2, bottom - u.y0) : 0u;
+    }
     u.tile_pixels = u.tile_w * u.tile_h;
     u.rel_begin = chunk * A->frames_per_unit;
     const uint32_t rel_count = min(A->frames_per_unit, A->n_frames - u.rel_begin);
@@ -969,14 +980,26 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
 // consecutive dispatches) and, if asked, runs the display tail of the last frame (:337-342).
 __global__ __launch_bounds__(kBlockThreads) void rt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ partial,
                                                                 uint32_t* __restrict__ output, size_t image_pixels,
-                                                                size_t first, uint32_t count, uint32_t n_frames,
-                                                                float sample_count)
+                                                                uint32_t width, uint32_t height, RowSet rows, uint32_t count,
+                                                                uint32_t n_frames, float sample_count)
 {
     uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x;
     if (i >= count) {
         return;
     }
-    const size_t texel = first + i;
+    size_t texel;
+    if (rows.stripe_rows == 0u) {
+        texel = (size_t)rows.row_begin * width + i;
+    } else {
+        // i counts the texels of this launch's stripes, stripe after stripe
+        const uint32_t stripe_texels = rows.stripe_rows * width;
+        const uint32_t k = i / stripe_texels;
+        const uint32_t within = i - k * stripe_texels;
+        texel = (size_t)(rows.stripe_first + k * rows.stripe_stride) * stripe_texels + within;
+        if (texel >= (size_t)width * height) {
+            return; // the part of the last stripe below the image
+        }
+    }
     const float4 prev = accum[texel];
     f3 total = mk(prev.x, prev.y, prev.z);
     for (uint32_t f = 0; f < n_frames; ++f) {
@@ -1133,7 +1156,10 @@ void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStrea
 hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
 {
     TraceArgs args = args_in;
-    const uint32_t rows = args.row_end - args.row_begin;
+    if (args.stripe_rows != 0u && (args.stripe_stride == 0u || (uint64_t)args.n_stripes * args.stripe_rows > 0x7FFFFFFFull)) {
+        return hipErrorInvalidValue;
+    }
+    const uint32_t rows = args.stripe_rows != 0u ? args.n_stripes * args.stripe_rows : args.row_end - args.row_begin;
     if (rows == 0 || args.n_frames == 0) {
         return hipSuccess;
     }
@@ -1158,6 +1184,13 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         }
         args.tile_h_log2 = (log2_pixels + 1u) / 2u;
         args.tile_w_log2 = log2_pixels - args.tile_h_log2;
+    }
+    // a tile must not straddle two stripes: its height divides stripe_rows (wider instead, up to 8)
+    while (args.stripe_rows != 0u && args.stripe_rows % (1u << args.tile_h_log2) != 0u) {
+        --args.tile_h_log2;
+        if (args.tile_w_log2 < 3u) {
+            ++args.tile_w_log2;
+        }
     }
     const uint32_t tile_w = 1u << args.tile_w_log2, tile_h = 1u << args.tile_h_log2;
     args.tiles_x = (args.width + tile_w - 1u) / tile_w;
@@ -1228,15 +1261,20 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, size_t image_pixels, size_t first,
-                       uint32_t count, uint32_t n_frames, float sample_count, hipStream_t stream)
+hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, uint32_t width, uint32_t height,
+                       const RowSet& rows, uint32_t n_frames, float sample_count, hipStream_t stream)
 {
+    const uint64_t n_rows = rows.stripe_rows != 0u ? (uint64_t)rows.n_stripes * rows.stripe_rows : rows.row_end - rows.row_begin;
+    const uint64_t count = n_rows * width;
     if (count == 0 || n_frames == 0) {
         return hipSuccess;
     }
-    const uint32_t blocks = (count + kBlockThreads - 1) / kBlockThreads;
-    hipLaunchKernelGGL(rt_fold_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, accum, partial, output, image_pixels,
-                       first, count, n_frames, sample_count);
+    if (count > 0xFFFFFFFFull) {
+        return hipErrorInvalidValue;
+    }
+    const uint32_t blocks = (uint32_t)((count + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL(rt_fold_kernel, dim3(blocks), dim3(kBlockThreads), 0, stream, accum, partial, output,
+                       (size_t)width * height, width, height, rows, (uint32_t)count, n_frames, sample_count);
     return hipGetLastError();
 }
 

@@ -42,6 +42,13 @@ struct TraceArgs {
     uint32_t height;
     uint32_t row_begin;
     uint32_t row_end;
+    // Interleaved rows (stripe_rows != 0): the image is cut into stripes of stripe_rows rows and the
+    // launch renders stripes stripe_first, stripe_first + stripe_stride, ... (n_stripes of them);
+    // row_begin/row_end are then ignored.  A stripe cut short by the bottom of the image is allowed.
+    uint32_t stripe_rows;
+    uint32_t stripe_first;
+    uint32_t stripe_stride;
+    uint32_t n_stripes;
     uint32_t first_frame;
     uint32_t n_frames;
     uint32_t frame_stride;
@@ -56,8 +63,17 @@ struct TraceArgs {
 
 size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds);
 hipError_t launch_trace(const TraceArgs& args, hipStream_t stream);
-hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, size_t image_pixels, size_t first,
-                       uint32_t count, uint32_t n_frames, float sample_count, hipStream_t stream);
+// Rows a launch covers: a contiguous band, or every stripe_stride-th stripe of stripe_rows rows.
+struct RowSet {
+    uint32_t row_begin = 0;
+    uint32_t row_end = 0;
+    uint32_t stripe_rows = 0; // 0 = the band [row_begin, row_end)
+    uint32_t stripe_first = 0;
+    uint32_t stripe_stride = 1;
+    uint32_t n_stripes = 0;
+};
+hipError_t launch_fold(float4* accum, const float4* partial, uint32_t* output, uint32_t width, uint32_t height,
+                       const RowSet& rows, uint32_t n_frames, float sample_count, hipStream_t stream);
 int stats_section_count();
 int stats_phase_count();
 hipError_t launch_resolve(const float4* accum, uint32_t* output, uint32_t first, uint32_t count,

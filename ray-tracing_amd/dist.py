@@ -6,6 +6,10 @@ texel depends only on (x, y, frame) (:310-311), so there are two exact ways to s
 
 * row bands:   rank r renders rows [b_r, b_{r+1}) of every frame; the bands are then gathered
                (all_gather of contiguous float4 slabs).  Bit-identical to one GPU.
+* stripes:     the same with interleaved rows: the image is cut into stripes of a few rows and rank r
+               renders stripes r, r+G, r+2G, ... (rt_render_stripes), so that cheap sky rows and
+               expensive ground rows are spread evenly; one all_gather_into_tensor of equal-sized
+               packed shards and a de-interleaving copy put the image together.  Bit-identical too.
 * frame split: rank r renders frames r, r+G, r+2G, ... of the whole image into its own zeroed
                accumulator; the accumulators are summed (all_reduce, fp32) and alpha is set back
                to 1 (the shader stores alpha = 1 every frame, :335).  RNG streams are identical to
@@ -52,6 +56,61 @@ def gather_row_bands(accum, bands, group=None):
                                        group=group, async_op=True))
     for w in work:
         w.wait()
+    return accum
+
+
+def stripe_count(height, stripe_rows):
+    return (height + stripe_rows - 1) // stripe_rows
+
+
+def stripes_of_rank(height, stripe_rows, world_size, rank):
+    """Indices of the stripes rank `rank` renders: rank, rank + world_size, ..."""
+    return list(range(rank, stripe_count(height, stripe_rows), world_size))
+
+
+def _all_gather_into(recv, send, group):
+    """all_gather_into_tensor; device tensors on a backend without device support for it (gloo, used to
+    rehearse several ranks on one GPU) go through host copies."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        recv.copy_(host)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
+def gather_stripes(accum, stripe_rows, group=None):
+    """accum: (H, W, C) tensor whose stripes rank, rank + G, ... (stripes of stripe_rows rows; the last
+    one may be cut short by the image) are valid on this rank.  After the call every rank holds the
+    complete image.  One collective: each rank packs its stripes into a (K, stripe_rows, W, C) buffer,
+    K = ceil(stripes / G), and the gathered (G, K, ...) buffer is copied back with ranks and slots
+    swapped -- for the stripes of complete rounds that is a single strided copy."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    height, width, channels = accum.shape
+    n_stripes = stripe_count(height, stripe_rows)
+    slots = (n_stripes + world - 1) // world
+    if world == 1:
+        return accum
+    full_rounds = (height // stripe_rows) // world      # rounds in which every rank owns a complete stripe
+    rows_in_rounds = full_rounds * world * stripe_rows
+    send = accum.new_zeros((slots, stripe_rows, width, channels))
+    if full_rounds:
+        rounds = accum[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels)
+        send[:full_rounds].copy_(rounds[:, rank])
+    for stripe in range(full_rounds * world, n_stripes):
+        if stripe % world == rank:
+            rows = accum[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
+            send[stripe // world, :rows.shape[0]].copy_(rows)
+    # (the collective wants the ranks' contributions concatenated along the first dimension)
+    flat = accum.new_empty((world * slots, stripe_rows, width, channels))
+    _all_gather_into(flat, send, group)
+    recv = flat.view(world, slots, stripe_rows, width, channels)
+    if full_rounds:
+        rounds.copy_(recv[:, :full_rounds].permute(1, 0, 2, 3, 4))
+    for stripe in range(full_rounds * world, n_stripes):
+        rows = accum[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
+        rows.copy_(recv[stripe % world, stripe // world, :rows.shape[0]])
     return accum
 
 

@@ -68,6 +68,7 @@ ABI = {
     "rt_render": (ctypes.c_int, [_H, _U32, _STREAM]),
     "rt_render_frames": (ctypes.c_int, [_H, _U32, _U32, _STREAM]),
     "rt_render_shard": (ctypes.c_int, [_H, _U32, _U32, _U32, _U32, _U32, ctypes.c_int, _STREAM]),
+    "rt_render_stripes": (ctypes.c_int, [_H, _U32, _U32, _U32, _U32, _U32, _U32, ctypes.c_int, _STREAM]),
     "rt_resolve_output": (ctypes.c_int, [_H, _U32, _U32, _U32, _STREAM]),
     "rt_resolve_output_from": (ctypes.c_int, [_H, ctypes.c_void_p, _U32, _U32, _U32, _STREAM]),
     "rt_accum_device_ptr": (ctypes.c_void_p, [_H]),
@@ -77,6 +78,7 @@ ABI = {
     "rt_read_output": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_size_t, _STREAM]),
     "rt_enable_rng_capture": (ctypes.c_int, [_H, ctypes.c_int]),
     "rt_read_rng_state": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_size_t, _STREAM]),
+    "rt_debug_fail_allocation": (None, [ctypes.c_int]),
     "rt_synchronize": (ctypes.c_int, [_H, _STREAM]),
     "rt_get_extent": (ctypes.c_int, [_H, ctypes.POINTER(_U32), ctypes.POINTER(_U32)]),
     "rt_last_kernel_ms": (ctypes.c_float, [_H]),
@@ -250,6 +252,14 @@ class RayTracer:
             row_end = self.extent[1]
         self._check(self._lib.rt_render_shard(self._h, int(first_frame), int(n_frames), int(frame_stride),
                                               int(row_begin), int(row_end), 1 if write_output else 0, self._stream))
+
+    def render_stripes(self, first_frame, n_frames, frame_stride=1, stripe_rows=8, stripe_first=0, stripe_stride=1,
+                       write_output=True):
+        """Every stripe_stride-th stripe of stripe_rows rows, starting at stripe stripe_first (rank r of G
+        passes stripe_first=r, stripe_stride=G)."""
+        self._check(self._lib.rt_render_stripes(self._h, int(first_frame), int(n_frames), int(frame_stride),
+                                                int(stripe_rows), int(stripe_first), int(stripe_stride),
+                                                1 if write_output else 0, self._stream))
 
     def resolve_output(self, sample_count, row_begin=0, row_end=None):
         if row_end is None:

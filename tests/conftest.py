@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch first: it brings its own copy of the HIP runtime, and whichever copy a process loads first is the
+# one every later library binds to.  With the tracer's library loaded first, torch finds no GPU.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -43,6 +43,14 @@ def _worker(rank, world, port, mode, result_path):
                 pyoracle.render(host.get_params_words(f), scene, accum=accum, y0=b, y1=e, want_output=False, nthreads=2)
             t = torch.from_numpy(accum)
             rtdist.gather_row_bands(t, bands)
+        elif mode.startswith("stripes"):
+            stripe_rows = int(mode[len("stripes"):])
+            for stripe in rtdist.stripes_of_rank(H, stripe_rows, world, rank):
+                b, e = stripe * stripe_rows, min(H, (stripe + 1) * stripe_rows)
+                for f in range(FRAMES):
+                    pyoracle.render(host.get_params_words(f), scene, accum=accum, y0=b, y1=e, want_output=False, nthreads=2)
+            t = torch.from_numpy(accum)
+            rtdist.gather_stripes(t, stripe_rows)
         else:
             first, count, stride = rtdist.frame_shard(0, FRAMES // world, world, rank)
             for k in range(count):
@@ -75,14 +83,15 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("mode", ["rows", "frames"])
-def test_two_rank_sharding(pkg, oracle, tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("rows", 2), ("frames", 2), ("stripes4", 2), ("stripes8", 3), ("stripes16", 2)])
+def test_two_rank_sharding(pkg, oracle, tmp_path, mode, world):
+    # H = 44: 11 stripes of 4 rows (odd count), 6 of 8 rows with the last cut to 4, 3 of 16 with the last cut to 12
     result = str(tmp_path / ("%s.npy" % mode))
-    mp.spawn(_worker, args=(2, _free_port(), mode, result), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, result), nprocs=world, join=True)
     got = np.load(result)
     ref = _single_process_reference(pkg, oracle)
     assert np.all(got[..., 3] == 1.0)
-    if mode == "rows":
+    if mode != "frames":
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     else:
         rmse = float(np.sqrt(np.mean((got[..., :3] - ref[..., :3]) ** 2)))
@@ -101,3 +110,6 @@ def test_row_bands_partition(pkg):
                 assert b == c and a <= b and c <= d
             assert all(b % 8 == 0 for (_, b) in bands[:-1] if b != height)
     assert rtdist.frame_shard(128, 64, 8, 3) == (131, 64, 8)
+    for height, stripe_rows, world in ((1080, 4, 8), (4320, 16, 8), (44, 8, 3), (5, 8, 4)):
+        seen = sorted(s for r in range(world) for s in rtdist.stripes_of_rank(height, stripe_rows, world, r))
+        assert seen == list(range(rtdist.stripe_count(height, stripe_rows)))

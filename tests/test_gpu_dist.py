@@ -1,0 +1,156 @@
+"""The multi-GPU path on real hardware, as far as one GPU allows: the RCCL leg on a one-rank process group
+(tensors that alias the tracer's device images, the sum-reduction, the resolve of a reduced image), and the
+sharded renders plus their collectives with two rank processes that share the GPU (gloo carries the
+collective there; RCCL refuses two ranks on one device).  Needs a real MI355X."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import make_tracer, oracle_frames, same
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP, DEPTH, FRAMES = 160, 100, 2, 8, 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_rccl_leg_on_a_one_rank_group(pkg, oracle):
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import dist as rtdist
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
+    try:
+        t = make_tracer(pkg, W, H, SPP, DEPTH)
+        t.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        accum = rtdist.accum_tensor(t, device)
+        output = rtdist.output_tensor(t, device)
+        assert accum.shape == (H, W, 4) and accum.dtype == torch.float32 and accum.data_ptr() == t.accum_device_ptr()
+        # the aliasing tensor sees what the kernel wrote
+        t.render_shard(0, FRAMES, 1, 0, H, write_output=False)
+        torch.cuda.synchronize(device)
+        got = t.read_accum()
+        assert same(accum.cpu().numpy(), got)
+        ref = oracle_frames(oracle, t, pkg.default_scene(), range(FRAMES))
+        assert same(got, ref["accum"])
+        # sum-reduction over the (one-rank) RCCL group into a second buffer, alpha back to 1
+        accum[..., 3] = 5.0
+        reduced = torch.empty_like(accum)
+        rtdist.reduce_frame_split(accum, out=reduced)
+        torch.cuda.synchronize(device)
+        assert same(reduced.cpu().numpy(), ref["accum"])
+        # the display tail on the reduced buffer == the oracle's image of the same frames
+        t.resolve_output_from(reduced.data_ptr(), FRAMES * SPP)
+        torch.cuda.synchronize(device)
+        assert same(t.read_output(), ref["output"])
+        assert same(output.cpu().numpy(), ref["output"])
+        # stripes on a one-rank group: the gather is the identity
+        t.reset_accumulation()
+        t.render_stripes(0, FRAMES, 1, 4, 0, 1, write_output=False)
+        rtdist.gather_stripes(accum, 4)
+        torch.cuda.synchronize(device)
+        assert same(accum.cpu().numpy(), ref["accum"])
+        # an all_gather_into_tensor on device memory the library owns
+        flat = torch.empty((H, W, 4), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(flat, accum)
+        torch.cuda.synchronize(device)
+        assert same(flat.cpu().numpy(), ref["accum"])
+        t.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, mode, result_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import rtamd_loader
+    pkg = rtamd_loader.load()
+    from raytracing_amd import dist as rtdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        t = pkg.RayTracer().create(W, H, device_id=0)
+        t.set_samples_per_pixel(SPP)
+        t.set_max_depth(DEPTH)
+        t.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        accum = rtdist.accum_tensor(t, device)
+        if mode == "tiles":
+            t.render_stripes(0, FRAMES, 1, 8, rank, world, write_output=False)
+            rtdist.gather_stripes(accum, 8)
+            t.resolve_output(FRAMES * SPP)
+            image = accum
+        elif mode == "bands":
+            bands = rtdist.row_bands(H, world)
+            t.render_shard(0, FRAMES, 1, bands[rank][0], bands[rank][1], write_output=False)
+            rtdist.gather_row_bands(accum, bands)
+            t.resolve_output(FRAMES * SPP)
+            image = accum
+        else:
+            t.render_shard(rank, len(range(rank, FRAMES, world)), world, 0, H, write_output=False)
+            image = torch.empty_like(accum)
+            rtdist.reduce_frame_split(accum, out=image)
+            t.resolve_output_from(image.data_ptr(), FRAMES * SPP)
+        torch.cuda.synchronize(device)
+        if rank == 0:
+            np.savez(result_path, accum=image.cpu().numpy(), output=t.read_output())
+        t.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,world", [("tiles", 2), ("tiles", 3), ("bands", 2), ("frames", 2)])
+def test_rank_processes_sharing_the_gpu(pkg, oracle, tmp_path, mode, world):
+    import torch.multiprocessing as mp
+    result = str(tmp_path / ("%s%d.npz" % (mode, world)))
+    mp.spawn(_worker, args=(world, _free_port(), mode, result), nprocs=world, join=True)
+    got = np.load(result)
+    host = pkg.RayTracer().create(W, H, device_id=-1)
+    host.set_samples_per_pixel(SPP)
+    host.set_max_depth(DEPTH)
+    ref = oracle_frames(oracle, host, pkg.default_scene(), range(FRAMES))
+    assert np.all(got["accum"][..., 3] == 1.0)
+    if mode == "frames":
+        lum = float(ref["accum"][..., :3].mean())
+        rmse = float(np.sqrt(np.mean((got["accum"][..., :3] - ref["accum"][..., :3]) ** 2)))
+        assert rmse <= 1e-3 * lum
+        assert np.abs(got["output"].astype(np.int32) - ref["output"].astype(np.int32)).max() <= 1
+    else:
+        assert same(got["accum"], ref["accum"])
+        assert same(got["output"], ref["output"])
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`bench.py --gpus 2` without a launcher: two rank processes, one JSON line.  (Both ranks share the
+    one GPU of this box and gloo carries the collective; on a multi-GPU node the same command line minus
+    the two rehearsal flags runs one rank per GPU over RCCL.)"""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--same-device", "--backend", "gloo"], env=env, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["samples_per_step"] == 1920 * 1080 * 16 * 64

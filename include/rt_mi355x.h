@@ -175,6 +175,24 @@ int rt_render_stripes(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint
                       uint32_t stripe_rows, uint32_t stripe_first, uint32_t stripe_stride, int write_output,
                       void *stream);
 
+/* rt_render_frames for callers that cannot allocate device memory (under HIP
+ * graph capture, in a tight serving loop, in harnesses that forbid hipMalloc):
+ * the per-frame sums of a multi-frame launch and the unit counter of the
+ * hierarchy kernel live in a file-scope device array of
+ * rt_static_scratch_bytes() bytes (64 MiB) that every GPU the library runs on
+ * holds from rt_create until the process ends, and the call allocates and frees
+ * nothing.  Same accumulator, RNG and output bits as rt_render_frames.  The
+ * frames are traced in groups of as many as the array holds at a time; a call
+ * with n_frames > 1 on an image of which two frames do not fit (more than
+ * rt_static_scratch_bytes() / 32 = 2 097 152 pixels; 1920x1080 still fits) is
+ * rejected with RT_ERR_BAD_ARGUMENT and a message that states both sizes.  All
+ * handles of one GPU share the array: calls that overlap in time on one GPU
+ * (different handles or streams) race.  It has no counterpart in the reference,
+ * whose Vulkan path allocates at create/resize only
+ * (src/rt/RayTracer.cpp:498-527). */
+int rt_render_frames_static(rt_handle h, uint32_t first_frame, uint32_t n_frames, void *stream);
+size_t rt_static_scratch_bytes(void);
+
 /* The display tail of the shader alone, raytrace.comp.glsl:337-342: divides the
  * accumulator by float(sample_count), applies c/(c+1) and pow(max(c,0),1/2.2),
  * stores rgba8 for rows [row_begin,row_end).  sample_count is the shader's

@@ -507,8 +507,10 @@ int clear_rows(rt_tracer* h, const rt::RowSet& rows, hipStream_t stream)
     return RT_OK;
 }
 
+// static_scratch: per-frame sums and the unit counter live in the library's file-scope device array
+// instead of allocations owned by the handle, and nothing is allocated or freed.
 int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride,
-                const rt::RowSet& rows, bool write_output, hipStream_t stream)
+                const rt::RowSet& rows, bool write_output, hipStream_t stream, bool static_scratch = false)
 {
     if (rows.stripe_rows == 0) {
         if (rows.row_begin > rows.row_end || rows.row_end > h->height) {
@@ -547,12 +549,31 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     float4* partial = h->partial;
     uint32_t* unit_counter = h->d_unit_counter;
     uint32_t group = n_frames;
+    if (static_scratch) {
+        void* base = nullptr;
+        size_t bytes = 0;
+        RT_HIP_TRY(h, rt::static_scratch(h->device, &base, &bytes));
+        unit_counter = static_cast<uint32_t*>(base);
+        partial = reinterpret_cast<float4*>(static_cast<unsigned char*>(base) + rt::kStaticScratchHeader);
+        const size_t room = bytes - rt::kStaticScratchHeader;
+        if (n_frames > 1) {
+            if (2 * frame_bytes > room) {
+                char buf[200];
+                std::snprintf(buf, sizeof(buf), "two frames of %ux%u need %zu bytes of per-frame sums, the static scratch holds %zu "
+                              "(at most %zu pixels); use rt_render_frames", h->width, h->height, 2 * frame_bytes, room,
+                              room / (2 * sizeof(float4)));
+                return fail_arg(h, buf);
+            }
+            group = static_cast<uint32_t>(std::min<size_t>(n_frames, room / frame_bytes));
+        }
+    }
+
     // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
     // accumulator in frame order afterwards; the frames of one call are split into groups so that
     // this image stays within a budget: 16 GiB (a 64-frame batch at 3840x2160 is 8.5 GB and should
     // stay one launch on a 288 GB device), at most a quarter of the memory that is free when the
     // buffer has to grow, or what RT_PARTIAL_BYTES says.
-    if (n_frames > 1) {
+    if (n_frames > 1 && !static_scratch) {
         size_t budget = static_cast<size_t>(16) << 30;
         if (const char* e = std::getenv("RT_PARTIAL_BYTES")) {
             budget = static_cast<size_t>(std::strtoull(e, nullptr, 10));
@@ -734,6 +755,11 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_start[i]));
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_stop[i]));
             }
+            // the library's set-up per device: the address of the file-scope scratch array that
+            // rt_render_frames_static works in (each device holds its own copy)
+            void* scratch = nullptr;
+            size_t scratch_bytes = 0;
+            RT_HIP_TRY(h, rt::static_scratch(device_id, &scratch, &scratch_bytes));
             int r = install_scene(h, std::move(scene));
             if (r != RT_OK) {
                 return r;
@@ -1046,6 +1072,19 @@ int rt_render_stripes(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint
         return RT_OK; // more shards than stripes: nothing to render for this one
     }
     return render_impl(h, first_frame, n_frames, frame_stride, rows, write_output != 0, static_cast<hipStream_t>(stream));
+}
+
+int rt_render_frames_static(rt_handle h, uint32_t first_frame, uint32_t n_frames, void* stream)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    return render_impl(h, first_frame, n_frames, 1, band(0, h->height), true, static_cast<hipStream_t>(stream), true);
+}
+
+size_t rt_static_scratch_bytes(void)
+{
+    return rt::kStaticScratchBytes - rt::kStaticScratchHeader;
 }
 
 namespace {

@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace rt {
 
@@ -1100,6 +1101,48 @@ __global__ void rt_probe_rng_kernel(const uint32_t* xyz, uint32_t n, uint32_t dr
 }
 
 } // namespace
+
+// ---- scratch of the allocation-free entry point (rt_render_frames_static) ----------------------
+// Device memory that exists from the moment the code object is loaded, so that callers which must not
+// call hipMalloc (under HIP graph capture, in tight serving loops) can still render several frames per
+// launch.  In host code the array's name only stands for the symbol: the device address comes from
+// hipGetSymbolAddress, per device, and is what kernels, memsets and copies are given.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+} // namespace
+
+hipError_t static_scratch(int device, void** ptr, size_t* bytes)
+{
+    if (device < 0 || device >= kMaxDevices || ptr == nullptr) {
+        return hipErrorInvalidValue;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device] == nullptr) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) {
+            return e;
+        }
+        if (current != device) {
+            return hipErrorInvalidDevice; // each device holds its own copy at its own address
+        }
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) {
+            return e;
+        }
+        g_scratch_ptr[device] = p;
+    }
+    *ptr = g_scratch_ptr[device];
+    if (bytes != nullptr) {
+        *bytes = kStaticScratchBytes;
+    }
+    return hipSuccess;
+}
 
 size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
 {

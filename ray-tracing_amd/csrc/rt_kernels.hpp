@@ -61,6 +61,14 @@ struct TraceArgs {
     uint32_t n_chunks;
 };
 
+// The file-scope device array behind rt_render_frames_static: kStaticScratchHeader bytes for the unit
+// counter, then room for per-frame sums.  Each device holds its own copy for the life of the process.
+constexpr size_t kStaticScratchHeader = 256;
+constexpr size_t kStaticScratchBytes = kStaticScratchHeader + (static_cast<size_t>(64) << 20);
+// Device address and size of that array on `device`, which must be the current device; looked up once
+// per device.
+hipError_t static_scratch(int device, void** ptr, size_t* bytes);
+
 size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds);
 hipError_t launch_trace(const TraceArgs& args, hipStream_t stream);
 // Rows a launch covers: a contiguous band, or every stripe_stride-th stripe of stripe_rows rows.

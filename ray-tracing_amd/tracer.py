@@ -69,6 +69,8 @@ ABI = {
     "rt_render_frames": (ctypes.c_int, [_H, _U32, _U32, _STREAM]),
     "rt_render_shard": (ctypes.c_int, [_H, _U32, _U32, _U32, _U32, _U32, ctypes.c_int, _STREAM]),
     "rt_render_stripes": (ctypes.c_int, [_H, _U32, _U32, _U32, _U32, _U32, _U32, ctypes.c_int, _STREAM]),
+    "rt_render_frames_static": (ctypes.c_int, [_H, _U32, _U32, _STREAM]),
+    "rt_static_scratch_bytes": (ctypes.c_size_t, []),
     "rt_resolve_output": (ctypes.c_int, [_H, _U32, _U32, _U32, _STREAM]),
     "rt_resolve_output_from": (ctypes.c_int, [_H, ctypes.c_void_p, _U32, _U32, _U32, _STREAM]),
     "rt_accum_device_ptr": (ctypes.c_void_p, [_H]),
@@ -260,6 +262,11 @@ class RayTracer:
         self._check(self._lib.rt_render_stripes(self._h, int(first_frame), int(n_frames), int(frame_stride),
                                                 int(stripe_rows), int(stripe_first), int(stripe_stride),
                                                 1 if write_output else 0, self._stream))
+
+    def render_frames_static(self, first_frame, n_frames):
+        """render_frames without any device allocation: the work buffers live in the library's static
+        device array (see rt_render_frames_static)."""
+        self._check(self._lib.rt_render_frames_static(self._h, int(first_frame), int(n_frames), self._stream))
 
     def resolve_output(self, sample_count, row_begin=0, row_end=None):
         if row_end is None:

@@ -1,0 +1,70 @@
+"""rt_render_frames_static -- the entry point that allocates nothing (its per-frame sums and unit counter
+live in the library's file-scope device array) -- against rt_render_frames, through the C ABI: same
+accumulator floats, RNG words and rgba8 bytes, on two calls in a row that share the array, the second
+with a smaller input.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import make_tracer, same
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(pkg, w, h, spp, depth, scene=None):
+    a = make_tracer(pkg, w, h, spp, depth, 0.05, scene=scene)
+    b = make_tracer(pkg, w, h, spp, depth, 0.05, scene=scene)
+    a.enable_rng_capture(True)
+    b.enable_rng_capture(True)
+    return a, b
+
+
+def _same_images(a, b):
+    assert same(a.read_rng_state(), b.read_rng_state())
+    assert same(a.read_accum(), b.read_accum())
+    assert same(a.read_output(), b.read_output())
+
+
+def test_static_scratch_entry_point_matches_render_frames(pkg):
+    lib = pkg.load_library()
+    room = lib.rt_static_scratch_bytes()
+    assert room == 64 << 20
+    # first call: 640x360, 40 frames = 147 MB of per-frame sums -> three groups through the 64 MiB array
+    ref, got = _pair(pkg, 640, 360, 2, 8)
+    ref.render_frames(0, 40)
+    got.render_frames_static(0, 40)
+    _same_images(ref, got)
+    # second call, smaller input, hierarchy scene (the unit counter lives in the array too); the array
+    # still holds the first call's sums
+    scene = pkg.synthetic_scene(200)
+    ref2, got2 = _pair(pkg, 200, 120, 3, 12, scene=scene)
+    ref2.render_frames(0, 5)
+    got2.render_frames_static(0, 5)
+    _same_images(ref2, got2)
+    # continuing an accumulation, single frames, and the first handle again after the second used the array
+    ref2.render_frames(5, 1)
+    got2.render_frames_static(5, 1)
+    _same_images(ref2, got2)
+    ref.render_frames(40, 7)
+    got.render_frames_static(40, 7)
+    _same_images(ref, got)
+    for t in (ref, got, ref2, got2):
+        t.destroy()
+
+
+def test_static_scratch_rejects_images_it_cannot_hold(pkg):
+    # two frames of 2048x1100 need 72 MB: more than the array; one frame needs no per-frame sums at all
+    t = make_tracer(pkg, 2048, 1100, 1, 4)
+    with pytest.raises(RuntimeError, match="static scratch holds"):
+        t.render_frames_static(0, 2)
+    t.render_frames_static(0, 1)
+    r = make_tracer(pkg, 2048, 1100, 1, 4)
+    r.render_frames(0, 1)
+    assert same(t.read_accum(), r.read_accum())
+    # 1920x1080 is the largest standard size of which two frames fit
+    u = make_tracer(pkg, 1920, 1080, 1, 4)
+    u.render_frames_static(0, 3)
+    v = make_tracer(pkg, 1920, 1080, 1, 4)
+    v.render_frames(0, 3)
+    assert same(u.read_accum(), v.read_accum())
+    for x in (t, r, u, v):
+        x.destroy()

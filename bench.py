@@ -126,6 +126,32 @@ def cpu_baseline(pkg, wl, budget_s=10.0):
                    "sample": "1280x720, 1 spp, depth 8, aperture 0.05, frames 0..%d (%.2f s)" % (c1_frames - 1, c1_dt)}}
 
 
+def other_call_patterns(pkg, device_index, stream):
+    """Outside the timed region: the same image rendered the way the reference's caller drives it
+    (src/core/App.cpp:403: one render(frame) per frame; consecutive calls overlap on the GPU), with the
+    benchmark's settings and with the application's defaults (4 spp, depth 12, aperture 0.05)."""
+    out = {}
+    for name, spp, depth, aperture in (("c2_one_render_call_per_frame", 16, 8, 0.0),
+                                       ("application_defaults_one_render_call_per_frame", 4, 12, 0.05)):
+        t = pkg.RayTracer().create(1920, 1080, device_id=device_index)
+        t.set_samples_per_pixel(spp)
+        t.set_max_depth(depth)
+        t.set_aperture(aperture)
+        t.set_stream(stream.cuda_stream)
+        frames = 64
+        for rep in range(2):
+            t.synchronize()
+            t0 = time.perf_counter()
+            for f in range(frames):
+                t.render(f)
+            t.synchronize()
+            dt = time.perf_counter() - t0
+        out[name] = {"ms_per_frame": dt / frames * 1e3, "samples_per_s": 1920 * 1080 * spp * frames / dt,
+                     "settings": "1920x1080, %d spp, depth %d, aperture %g, 64 rt_render calls" % (spp, depth, aperture)}
+        t.destroy()
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -161,6 +187,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--stripe-rows", type=int, default=0, help="rows per interleaved stripe in tiles mode (0: 4, or 16 at 8K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra call patterns (for profiling runs)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU code path (process group, collective, resolve) even with one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
@@ -170,6 +197,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+
+    # stdout carries the one JSON line and nothing else: whatever libraries print (RCCL's version banner,
+    # for one) is sent to stderr by pointing descriptor 1 there for the duration of the run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -181,6 +214,9 @@ def main():
     if args.scaling == "weak" and args.mode != "frames":
         sys.exit("--scaling weak needs --mode frames (a fixed image cannot grow with the ranks)")
 
+    # torch before the tracer's library: torch brings its own copy of the HIP runtime, and the copy a process
+    # loads first is the one that finds the GPU
+    import torch
     import rtamd_loader
     pkg = rtamd_loader.load()
 
@@ -189,7 +225,6 @@ def main():
     if rank == 0 and world == 1 and not args.force_distributed and not args.no_cpu_baseline:
         baseline = cpu_baseline(pkg, wl)
 
-    import torch
     from raytracing_amd import dist as rtdist
     device_index = 0 if args.same_device else local_rank
     torch.cuda.set_device(device_index)
@@ -216,28 +251,46 @@ def main():
 
     stripe_rows = args.stripe_rows or (16 if height >= 4000 else 4)
     accum = rtdist.accum_tensor(tracer, device) if distributed else None
-    reduced = torch.empty_like(accum) if distributed and args.mode == "frames" else None
+    # The collective of a step runs on a side stream into a second image, and the display resolve reads that
+    # image: the accumulator is only read while a rank's shard is packed, so the next step's render starts as
+    # soon as the packing is done and runs beside the collective.
+    image = torch.empty_like(accum) if distributed else None
+    comm = torch.cuda.Stream(device) if distributed else None
+    packed = None
     frames_per_step = frames * world if args.scaling == "weak" else frames
 
     def step(index):
+        nonlocal packed
         base = index * frames_per_step
         if not distributed:
             tracer.render_frames(base, frames)
-        elif args.mode == "tiles":
-            # rank r: stripes r, r + world, ... of every frame of the step; then the image is put together
+            return
+        if packed is not None:
+            stream.wait_event(packed)      # the previous step's shard has been read out of the accumulator
+        if args.mode == "tiles":
+            # rank r: stripes r, r + world, ... of every frame of the step
             tracer.render_stripes(base, frames, 1, stripe_rows, rank, world, write_output=False)
-            rtdist.gather_stripes(accum, stripe_rows)
-            tracer.resolve_output((base + frames) * spp)
         else:
-            # rank r: frames base + r, base + r + world, ... of the whole image; then the partial sums are added
+            # rank r: frames base + r, base + r + world, ... of the whole image
             count = len(range(rank, frames_per_step, world))
             if count:
                 tracer.render_shard(base + rank, count, world, 0, height, write_output=False)
-            rtdist.reduce_frame_split(accum, out=reduced)
-            tracer.resolve_output_from(reduced.data_ptr(), (base + frames_per_step) * spp)
+        rendered = torch.cuda.Event()
+        rendered.record(stream)
+        packed = torch.cuda.Event()
+        with torch.cuda.stream(comm):
+            comm.wait_event(rendered)
+            tracer.set_stream(comm.cuda_stream)
+            if args.mode == "tiles":
+                rtdist.gather_stripes(accum, stripe_rows, out=image, packed=packed)   # the image is put together
+            else:
+                rtdist.reduce_frame_split(accum, out=image, packed=packed)            # the partial sums are added
+            tracer.resolve_output_from(image.data_ptr(), (base + frames_per_step) * spp)
+            tracer.set_stream(stream.cuda_stream)
 
     def fence():
         if distributed:
+            comm.synchronize()
             if args.backend == "nccl":
                 dist.barrier(device_ids=[device_index])
             else:
@@ -323,9 +376,12 @@ def main():
                                   "note": "no algorithmic FLOP count recorded for this workload (tools/count_flops.py)"}
         if distributed:
             result["rank_kernel_ms"] = {"min": kernel_spread[0], "max": kernel_spread[1]}
+        elif args.workload == "c2" and not args.no_extras:
+            result["other_call_patterns"] = other_call_patterns(pkg, device_index, stream)
         if baseline is not None:
             result["cpu_baseline"] = baseline
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
 
     tracer.destroy()
     if distributed:

@@ -143,6 +143,19 @@ int rt_reset_accumulation(rt_handle h);
  * command buffer.  Successive calls on one stream are ordered. */
 int rt_render(rt_handle h, uint32_t frame_index, void *stream);
 
+/* Consecutive single-frame calls (rt_render, or a shard call with n_frames == 1)
+ * overlap on the GPU by default: the library traces call k on its own stream
+ * k % 2 into a per-frame sum image (two are kept per handle, 32 bytes per pixel)
+ * and adds the sums to the accumulator on the caller's stream in call order, so
+ * the end of one launch, when the GPU runs empty, is filled by the start of the
+ * next.  Accumulator, output and their ordering on the caller's stream are those
+ * of the plain dispatch (raytrace.comp.glsl:333-342).  enable = 0 keeps every
+ * launch on the caller's stream (for callers that capture the stream into a HIP
+ * graph).  The reference serialises its dispatches with a semaphore
+ * (src/core/App.cpp:163-168) because each one reads the accumulator; here only
+ * the short fold does. */
+int rt_set_frame_overlap(rt_handle h, int enable);
+
 /* n_frames consecutive rt_render calls (frame_index = first_frame ..
  * first_frame + n_frames - 1) as one launch: same accumulator bits, the output
  * image is that of the last frame.  This is the caller loop of

@@ -67,6 +67,18 @@ struct rt_tracer {
     uint32_t samples_per_pixel = 4;
     uint32_t max_depth = 12;
 
+    // Overlap of consecutive single-frame calls (how the reference's caller drives render,
+    // src/core/App.cpp:403): call k traces its frame on the library's own stream k % 2 into a per-frame
+    // sum image of its own, and the sums are folded into the accumulator on the caller's stream, in call
+    // order.  The drain phase of one launch then runs next to the start of the following one.
+    bool overlap_frames = true;
+    hipStream_t pipe_stream[2] = {};
+    hipEvent_t pipe_traced[2] = {};   // the trace of the slot has finished
+    hipEvent_t pipe_free[2] = {};     // the fold that read the slot has finished
+    bool pipe_used[2] = { false, false };
+    float4* pipe_partial = nullptr;   // two images of per-frame sums
+    uint64_t pipe_calls = 0;
+
     // HIP event pairs around the most recent trace launches (a ring), for rt_kernel_ms
     static constexpr uint32_t kTimedLaunches = 64;
     hipEvent_t ev_start[kTimedLaunches] = {};
@@ -249,8 +261,10 @@ struct Images {
     float4* accum = nullptr;
     uint32_t* output = nullptr;
     uint32_t* rng_state = nullptr;
+    float4* pipe_partial = nullptr;
     void release()
     {
+        if (pipe_partial) { (void)hipFree(pipe_partial); pipe_partial = nullptr; }
         if (accum) { (void)hipFree(accum); accum = nullptr; }
         if (output) { (void)hipFree(output); output = nullptr; }
         if (rng_state) { (void)hipFree(rng_state); rng_state = nullptr; }
@@ -263,6 +277,8 @@ void free_images(rt_tracer* h)
     if (h->output) { (void)hipFree(h->output); h->output = nullptr; }
     if (h->rng_state) { (void)hipFree(h->rng_state); h->rng_state = nullptr; }
     if (h->partial) { (void)hipFree(h->partial); h->partial = nullptr; h->partial_bytes = 0; }
+    if (h->pipe_partial) { (void)hipFree(h->pipe_partial); h->pipe_partial = nullptr; }
+    h->pipe_used[0] = h->pipe_used[1] = false;
 }
 
 // RayTracer::createAccumulationImage, src/rt/RayTracer.cpp:498-527 (+ the output image
@@ -275,6 +291,7 @@ int allocate_images(rt_tracer* h, uint32_t width, uint32_t height, Images& out)
         RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.accum), pixels * sizeof(float4)));
         RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.output), pixels * sizeof(uint32_t)));
         RT_HIP_TRY(h, hipMemset(out.output, 0, pixels * sizeof(uint32_t)));
+        RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.pipe_partial), 2 * pixels * sizeof(float4)));
         if (h->rng_capture) {
             RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.rng_state), pixels * sizeof(uint32_t)));
             RT_HIP_TRY(h, hipMemset(out.rng_state, 0, pixels * sizeof(uint32_t)));
@@ -642,6 +659,9 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         }
     }
 
+    // (not while the final RNG words are captured: two launches in flight would both store theirs)
+    const bool overlap = n_frames == 1 && !static_scratch && h->overlap_frames && !h->rng_capture && h->stats == nullptr &&
+                         h->pipe_partial != nullptr;
     for (uint32_t done = 0; done < n_frames; done += group) {
         const uint32_t count = std::min(group, n_frames - done);
         const uint32_t first = first_frame + done * frame_stride;
@@ -676,8 +696,38 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.tile_w_log2 = tile_w_log2;
         args.tile_h_log2 = tile_h_log2;
         args.tiles_x = args.n_tiles = args.n_chunks = 0;
+        args.unit_items = 0;
+        if (const char* e = std::getenv("RT_UNIT_ITEMS")) {
+            args.unit_items = static_cast<uint32_t>(std::max(1, std::atoi(e)));
+        }
+        args.reverse_units = std::getenv("RT_REVERSE_UNITS") != nullptr ? 1u : 0u;
 
         const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);
+        if (overlap) {
+            // this frame's samples are summed per pixel into the call's slot on one of the library's two
+            // streams (nothing there touches the accumulator, so it can run beside the previous call's
+            // launch), and added to the accumulator on the caller's stream: prev + sum, as :333-335 do
+            const uint32_t p = static_cast<uint32_t>(h->pipe_calls++ & 1u);
+            hipStream_t side = h->pipe_stream[p];
+            if (h->pipe_used[p]) {
+                RT_HIP_TRY(h, hipStreamWaitEvent(side, h->pipe_free[p], 0)); // the slot's previous sums have been folded
+            }
+            args.partial = h->pipe_partial + static_cast<size_t>(p) * image_pixels;
+            args.output = nullptr;
+            args.unit_counter = tree ? h->d_unit_counter + 16u * (1u + p) : nullptr;
+            RT_HIP_TRY(h, hipEventRecord(h->ev_start[slot], side));
+            RT_HIP_TRY(h, rt::launch_trace(args, side));
+            RT_HIP_TRY(h, hipEventRecord(h->ev_stop[slot], side));
+            ++h->launches;
+            RT_HIP_TRY(h, hipEventRecord(h->pipe_traced[p], side));
+            RT_HIP_TRY(h, hipStreamWaitEvent(stream, h->pipe_traced[p], 0));
+            const float sample_count = static_cast<float>((first + 1u) * h->samples_per_pixel); // :337
+            RT_HIP_TRY(h, rt::launch_fold(h->accum, args.partial, write_output ? h->output : nullptr, h->width, h->height,
+                                          rows, 1, sample_count, stream));
+            RT_HIP_TRY(h, hipEventRecord(h->pipe_free[p], stream));
+            h->pipe_used[p] = true;
+            continue;
+        }
         RT_HIP_TRY(h, hipEventRecord(h->ev_start[slot], stream));
         RT_HIP_TRY(h, rt::launch_trace(args, stream));
         RT_HIP_TRY(h, hipEventRecord(h->ev_stop[slot], stream));
@@ -755,6 +805,19 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_start[i]));
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_stop[i]));
             }
+            for (int i = 0; i < 2; ++i) {
+                // Streams of normal priority share a few hardware queues in turn (four per process by
+                // default), so with other streams alive two of them can land on the queue of the caller's
+                // stream and run behind it instead of beside it.  Streams of another priority get their
+                // queues from a pool of their own.
+                int least = 0, greatest = 0;
+                RT_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                const int priority = std::getenv("RT_PIPE_NORMAL_PRIORITY") != nullptr ? 0 : greatest;
+                RT_HIP_TRY(h, hipStreamCreateWithPriority(&h->pipe_stream[i], hipStreamNonBlocking, priority));
+                RT_HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_traced[i], hipEventDisableTiming));
+                RT_HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_free[i], hipEventDisableTiming));
+            }
+            h->overlap_frames = std::getenv("RT_NO_FRAME_OVERLAP") == nullptr;
             // the library's set-up per device: the address of the file-scope scratch array that
             // rt_render_frames_static works in (each device holds its own copy)
             void* scratch = nullptr;
@@ -772,6 +835,7 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
             h->accum = images.accum;
             h->output = images.output;
             h->rng_state = images.rng_state;
+            h->pipe_partial = images.pipe_partial;
             return RT_OK;
         };
         rc = body();
@@ -816,6 +880,7 @@ int rt_resize(rt_handle h, uint32_t width, uint32_t height)
     h->accum = images.accum;
     h->output = images.output;
     h->rng_state = images.rng_state;
+    h->pipe_partial = images.pipe_partial;
     h->width = width;
     h->height = height;
     h->reset_accum = true; // :228
@@ -839,6 +904,11 @@ int rt_destroy(rt_handle h)
         for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
             if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (h->pipe_traced[i]) { (void)hipEventDestroy(h->pipe_traced[i]); }
+            if (h->pipe_free[i]) { (void)hipEventDestroy(h->pipe_free[i]); }
+            if (h->pipe_stream[i]) { (void)hipStreamDestroy(h->pipe_stream[i]); }
         }
         (void)hipGetLastError();
     }
@@ -960,6 +1030,15 @@ int rt_set_scene_hierarchy(rt_handle h, int enable)
         return RT_ERR_BAD_ARGUMENT;
     }
     h->use_tree = enable != 0;
+    return RT_OK;
+}
+
+int rt_set_frame_overlap(rt_handle h, int enable)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    h->overlap_frames = enable != 0;
     return RT_OK;
 }
 

@@ -40,6 +40,7 @@
 #include "rt_tree.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -532,6 +533,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t n_units = A.n_tiles * A.n_chunks;
     const uint32_t wave_index = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     uint32_t unit = PERSISTENT == kByCounter ? next_unit(A.unit_counter) : wave_index;
+    if (PERSISTENT == kOneUnit && A.reverse_units != 0u && unit < n_units) {
+        unit = n_units - 1u - unit;
+    }
     const uint32_t first_unit = unit;
     const bool spare_wave = first_unit >= n_units;
     const uint32_t full_w = 1u << A.tile_w_log2, full_h = 1u << A.tile_h_log2;
@@ -1162,10 +1166,17 @@ namespace {
 // (160 KiB of LDS and 32 waves per compute unit).
 uint64_t resident_blocks(size_t lds, uint32_t waves_per_block)
 {
-    int device = 0, cus = 0;
-    if (hipGetDevice(&device) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) {
-        cus = 256;
+    // (the devices of one node are of one kind: the figure is looked up once per process)
+    static std::atomic<int> cached_cus{ 0 };
+    int cus = cached_cus.load();
+    if (cus == 0) {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        cached_cus.store(cus);
     }
     const uint64_t by_lds = std::max<uint64_t>(1u, (160u * 1024u) / std::max<size_t>(lds, 1u));
     const uint64_t by_waves = std::max<uint64_t>(1u, 32u / waves_per_block);
@@ -1220,10 +1231,29 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         // items.  Rays of neighbouring pixels, and of one pixel in several frames, walk the same nodes
         // (4096 spheres, 960 x 540, 4 frames: 8 x 8 pixels 31.3 ms, 4 x 8 22.5, 4 x 4 19.9, 2 x 4 19.4,
         // 2 x 2 20.2, 1 x 1 20.5).
-        const uint32_t target_items = args.tree_nodes != 0 ? 32u : 512u;
+        uint32_t target_items = args.tree_nodes != 0 ? 32u : 512u;
+        if (args.tree_nodes == 0) {
+            // A launch ends with a drain phase about as long as one unit (1 to 2 ms for 512 items of the
+            // benchmark), which a launch of 30 rounds of units does not notice and a launch of 4 rounds
+            // (one of eight shards of the image, say) pays with a third of its time.  Launches of fewer
+            // than 16 rounds of 512-item units get smaller units, down to 128 items (two per lane).
+            // Measured on the benchmark: the whole image 29.9 / 30.4 / 31.3 ms with units of 512 / 256 /
+            // 128 items, the eight stripe shards of it together 41.8 / 36.2 / 34.5 ms.
+            const uint64_t items = (uint64_t)args.width * rows * args.n_frames;
+            const uint64_t slots = resident_blocks(0, 1) * 16u;
+            while (target_items > 128u && items / target_items < slots) {
+                target_items >>= 1;
+            }
+        }
+        if (args.unit_items != 0u) {
+            target_items = args.unit_items;
+        }
         uint32_t log2_pixels = 6;
         while (log2_pixels > 3u && (args.frames_per_unit << log2_pixels) > target_items) {
             --log2_pixels;
+        }
+        if ((args.frames_per_unit << log2_pixels) > target_items) {
+            args.frames_per_unit = std::max(1u, target_items >> log2_pixels); // the smallest tile: fewer frames per unit
         }
         args.tile_h_log2 = (log2_pixels + 1u) / 2u;
         args.tile_w_log2 = log2_pixels - args.tile_h_log2;

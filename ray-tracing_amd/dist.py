@@ -79,48 +79,62 @@ def _all_gather_into(recv, send, group):
         dist.all_gather_into_tensor(recv, send, group=group)
 
 
-def gather_stripes(accum, stripe_rows, group=None):
+def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None):
     """accum: (H, W, C) tensor whose stripes rank, rank + G, ... (stripes of stripe_rows rows; the last
-    one may be cut short by the image) are valid on this rank.  After the call every rank holds the
-    complete image.  One collective: each rank packs its stripes into a (K, stripe_rows, W, C) buffer,
-    K = ceil(stripes / G), and the gathered (G, K, ...) buffer is copied back with ranks and slots
-    swapped -- for the stripes of complete rounds that is a single strided copy."""
+    one may be cut short by the image) are valid on this rank.  After the call `out` (default: accum
+    itself) holds the complete image on every rank.  One collective: each rank packs its stripes into a
+    (K, stripe_rows, W, C) buffer, K = ceil(stripes / G), and the gathered (G, K, ...) buffer is copied
+    back with ranks and slots swapped -- for the stripes of complete rounds that is a single strided copy.
+
+    With a separate `out`, accum is only read, and only while the shard is packed: `packed`, a
+    torch.cuda.Event, is recorded right after that, so that a caller who runs the gather on a side stream
+    can let the next render into accum start while the collective is still in flight."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     height, width, channels = accum.shape
+    target = accum if out is None else out
     n_stripes = stripe_count(height, stripe_rows)
     slots = (n_stripes + world - 1) // world
     if world == 1:
-        return accum
+        if target is not accum:
+            target.copy_(accum)
+        if packed is not None:
+            packed.record()
+        return target
     full_rounds = (height // stripe_rows) // world      # rounds in which every rank owns a complete stripe
     rows_in_rounds = full_rounds * world * stripe_rows
     send = accum.new_zeros((slots, stripe_rows, width, channels))
     if full_rounds:
-        rounds = accum[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels)
-        send[:full_rounds].copy_(rounds[:, rank])
+        send[:full_rounds].copy_(accum[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels)[:, rank])
     for stripe in range(full_rounds * world, n_stripes):
         if stripe % world == rank:
             rows = accum[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
             send[stripe // world, :rows.shape[0]].copy_(rows)
+    if packed is not None:
+        packed.record()
     # (the collective wants the ranks' contributions concatenated along the first dimension)
     flat = accum.new_empty((world * slots, stripe_rows, width, channels))
     _all_gather_into(flat, send, group)
     recv = flat.view(world, slots, stripe_rows, width, channels)
     if full_rounds:
-        rounds.copy_(recv[:, :full_rounds].permute(1, 0, 2, 3, 4))
+        target[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels).copy_(
+            recv[:, :full_rounds].permute(1, 0, 2, 3, 4))
     for stripe in range(full_rounds * world, n_stripes):
-        rows = accum[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
+        rows = target[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
         rows.copy_(recv[stripe % world, stripe // world, :rows.shape[0]])
-    return accum
+    return target
 
 
-def reduce_frame_split(accum, out=None, group=None):
+def reduce_frame_split(accum, out=None, group=None, packed=None):
     """Sums the per-rank accumulators of a frame split.  accum: (H, W, 4) float32.  Returns the
-    reduced image (in `out` if given, else in place) with alpha restored to 1."""
+    reduced image (in `out` if given, else in place) with alpha restored to 1.  With a separate `out`,
+    accum is only read by the copy that starts the call; `packed` (a torch.cuda.Event) is recorded after it."""
     if out is None:
         out = accum
     else:
         out.copy_(accum)
+    if packed is not None:
+        packed.record()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     out[..., 3] = 1.0
     return out

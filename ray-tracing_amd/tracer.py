@@ -63,6 +63,7 @@ ABI = {
     "rt_get_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.POINTER(_U32)]),
     "rt_get_scene_hierarchy_links": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _U32,
                                                     ctypes.POINTER(_U32)]),
+    "rt_set_frame_overlap": (ctypes.c_int, [_H, ctypes.c_int]),
     "rt_get_params": (ctypes.c_int, [_H, _U32, ctypes.POINTER(GPUParams)]),
     "rt_reset_accumulation": (ctypes.c_int, [_H]),
     "rt_render": (ctypes.c_int, [_H, _U32, _STREAM]),
@@ -209,6 +210,11 @@ class RayTracer:
         """Scenes of 24 spheres or more are traced through a bounding-sphere hierarchy (same images);
         enable=False tests every sphere against every ray like the shader's loop (raytrace.comp.glsl:247-259)."""
         self._check(self._lib.rt_set_scene_hierarchy(self._h, 1 if enable else 0))
+
+    def set_frame_overlap(self, enable):
+        """Consecutive single-frame calls overlap on the GPU (default); False keeps every launch on the
+        caller's stream."""
+        self._check(self._lib.rt_set_frame_overlap(self._h, 1 if enable else 0))
 
     def get_scene_hierarchy(self):
         """(geom (n, 4) float32, word (n,) uint32) of the current scene's hierarchy; n = 0 if it has none."""

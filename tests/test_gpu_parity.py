@@ -457,3 +457,41 @@ def test_frame_loop_replay_matches_oracle(pkg, oracle):
     assert loop.rendered == [0, 1, 0, 1, 2, 1, 0, 1, 2, 1, 2]
     assert same(got_acc, tap.accum)
     assert same(got_out, tap.out["output"])
+
+
+@pytest.mark.parametrize("scene_size", [5, 200])
+def test_overlapped_single_frame_calls(pkg, oracle, scene_size):
+    """Consecutive rt_render calls are traced on two internal streams and folded in call order: same bits
+    as with the overlap switched off and as the oracle, across resets, a shard call and a batch in between
+    (the 200-sphere scene goes through the hierarchy kernel, whose overlapping launches need a unit counter
+    each)."""
+    w, h = 192, 108
+    scene = pkg.default_scene() if scene_size == 5 else pkg.synthetic_scene(scene_size)
+    a = make_tracer(pkg, w, h, 3, 8, 0.05, scene=scene)
+    b = make_tracer(pkg, w, h, 3, 8, 0.05, scene=scene)
+    b.set_frame_overlap(False)
+    for t in (a, b):
+        for f in range(9):
+            t.render(f)
+    ref = oracle_frames(oracle, a, scene, range(9))
+    assert same(a.read_accum(), ref["accum"])
+    assert same(a.read_output(), ref["output"])
+    assert same(b.read_accum(), ref["accum"])
+    for t in (a, b):
+        t.render_frames(9, 3)           # a batch on the caller's stream between overlapped calls
+        t.render(12)
+        t.render_shard(13, 1, 1, 0, 50)
+        t.render_shard(13, 1, 1, 50, h)
+        t.render(14)
+    ref = oracle_frames(oracle, a, scene, range(9, 15), accum=ref["accum"])
+    assert same(a.read_accum(), ref["accum"])
+    assert same(a.read_output(), ref["output"])
+    assert same(b.read_accum(), a.read_accum())
+    a.set_fov(33.0)                     # reset in the middle of a run of overlapped calls
+    for f in (4, 5, 6):
+        a.render(f)
+    ref = oracle_frames(oracle, a, scene, (4, 5, 6))
+    assert same(a.read_accum(), ref["accum"])
+    assert same(a.read_output(), ref["output"])
+    a.destroy()
+    b.destroy()

@@ -700,7 +700,6 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         if (const char* e = std::getenv("RT_UNIT_ITEMS")) {
             args.unit_items = static_cast<uint32_t>(std::max(1, std::atoi(e)));
         }
-        args.reverse_units = std::getenv("RT_REVERSE_UNITS") != nullptr ? 1u : 0u;
 
         const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);
         if (overlap) {

@@ -444,6 +444,7 @@ __device__ __forceinline__ uint32_t next_unit(uint32_t* counter)
 // Unit number `unit` (chunk-major) of the launch, and the wave's tables of the hash terms of :37-44
 // for its columns, rows and frames (the seed of an item is hash(px) ^ hash(py) ^ hash(frame),
 // :310-311).  Every lane of the wave has to be active.
+template <bool STRIPES>
 __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, uint32_t unit, uint32_t* hash_tab)
 {
     (void)A_in_registers;
@@ -457,7 +458,7 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
     u.x0 = tile_x << A->tile_w_log2;
     u.tile_w = min(1u << A->tile_w_log2, A->width - u.x0);
     const uint32_t rel_row = tile_y << A->tile_h_log2;
-    if (A->stripe_rows == 0u) {
+    if (!STRIPES) {
         u.y0 = A->row_begin + rel_row;
         u.tile_h = min(1u << A->tile_h_log2, A->row_end - u.y0);
     } else {
@@ -497,7 +498,8 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
 // PERSISTENT = kOneUnit: the launch has as many waves as units (for the benchmark, waves that take
 // their next unit from a counter when their pool runs dry were measured 2.8 % slower);
 // kByCounter: the hierarchy kernels, see below.
-template <int MODE, class Stats, int BLOCK, int PERSISTENT>
+// STRIPES: the launch renders interleaved stripes of rows (TraceArgs::stripe_rows != 0) instead of one band.
+template <int MODE, class Stats, int BLOCK, int PERSISTENT, bool STRIPES>
 __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
     constexpr bool MAT_IN_LDS = MODE == kFullLds || MODE == kFullLds5;
@@ -533,13 +535,10 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t n_units = A.n_tiles * A.n_chunks;
     const uint32_t wave_index = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     uint32_t unit = PERSISTENT == kByCounter ? next_unit(A.unit_counter) : wave_index;
-    if (PERSISTENT == kOneUnit && A.reverse_units != 0u && unit < n_units) {
-        unit = n_units - 1u - unit;
-    }
     const uint32_t first_unit = unit;
     const bool spare_wave = first_unit >= n_units;
     const uint32_t full_w = 1u << A.tile_w_log2, full_h = 1u << A.tile_h_log2;
-    uint32_t n_items = load_unit(A, min(first_unit, n_units - 1u), hash_tab);
+    uint32_t n_items = load_unit<STRIPES>(A, min(first_unit, n_units - 1u), hash_tab);
     uint32_t next_item = 0; // wave-uniform pool cursor
     bool more_units = PERSISTENT != kOneUnit; // wave-uniform: the last unit has not been passed yet
     // both end with the workgroup barrier
@@ -760,7 +759,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             // everything they need in registers.
             unit = next_unit(args_in_memory()->unit_counter);
             if (unit < n_units) {
-                n_items = load_unit(A, unit, hash_tab);
+                n_items = load_unit<STRIPES>(A, unit, hash_tab);
                 next_item = 0;
             } else {
                 more_units = false;
@@ -839,8 +838,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 // only camera lanes in this wave (a tile of sky, typically): two draws per candidate
                 do {
                     st.section(ST_DISK_IT);
-                    const uint32_t s1 = 1664525u * rng + 1013904223u;
-                    rng = 1664525u * s1 + 1013904223u;
+                    const uint32_t s1 = lcg_step(rng, 1664525u, 1013904223u);
+                    rng = lcg_step(s1, 1664525u, 1013904223u);
                     mx = (float)((int32_t)(s1 & 0x00FFFFFFu) - 0x00800000);
                     my = (float)((int32_t)(rng & 0x00FFFFFFu) - 0x00800000);
                     m_dot = mx * mx + my * my;
@@ -848,9 +847,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             } else {
                 do {
                     st.section(ST_RIS_IT);
-                    const uint32_t s1 = 1664525u * rng + 1013904223u;
-                    const uint32_t s2 = 1664525u * s1 + 1013904223u;
-                    rng = mul3 * s2 + add3;
+                    const uint32_t s1 = lcg_step(rng, 1664525u, 1013904223u);
+                    const uint32_t s2 = lcg_step(s1, 1664525u, 1013904223u);
+                    rng = lcg_step(s2, mul3, add3);
                     mx = (float)((int32_t)(s1 & 0x00FFFFFFu) - 0x00800000);
                     my = (float)((int32_t)(s2 & 0x00FFFFFFu) - 0x00800000);
                     mz = (float)((int32_t)(rng & mask3) - off3);
@@ -904,8 +903,13 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
                 scattered = dot(rd, n) > 0.0f;
             }
             // common to both: origin p + 0.001 n (:160, :203) and attenuation = albedo (:170, :206)
+#ifdef RT_PK_SHADE
+            ro = pk_scale_add(p, n, 0.001f);
+            throughput = pk_mul(throughput, albedo);
+#else
             ro = p + n * 0.001f;
             throughput = throughput * albedo;
+#endif
         } else if (hit) {
             // scatterDielectric, :210-234
             st.section(ST_DIEL);
@@ -1199,10 +1203,14 @@ void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStrea
     }
     if (std::getenv("RT_DEBUG_OCCUPANCY") != nullptr) {
         int per_cu = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT>, BLOCK, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT, false>, BLOCK, lds);
         fprintf(stderr, "occupancy: %d workgroups of %d threads per CU, lds %zu, blocks %llu\n", per_cu, BLOCK, lds, (unsigned long long)blocks);
     }
-    hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
+    if (args.stripe_rows != 0u) {
+        hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT, true>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
+    } else {
+        hipLaunchKernelGGL((rt_trace_kernel<MODE, StatsPolicy, BLOCK, PERSISTENT, false>), dim3((uint32_t)blocks), dim3(BLOCK), lds, stream, args);
+    }
 }
 
 } // namespace

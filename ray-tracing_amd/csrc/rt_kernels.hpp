@@ -56,7 +56,6 @@ struct TraceArgs {
     uint32_t tile_w_log2;         // pixel tile of a unit, 2^w x 2^h with w, h <= 3; anything larger = let launch_trace choose
     uint32_t tile_h_log2;
     uint32_t unit_items;          // items a unit should pool (0 = launch_trace's default)
-    uint32_t reverse_units;       // hand the units out last to first (experiment: RT_REVERSE_UNITS)
     // filled in by launch_trace
     uint32_t tiles_x;
     uint32_t n_tiles;

@@ -8,6 +8,6 @@ for round in 1 2; do
     envargs=()
     IFS=',' read -ra parts <<< "$settings"
     for kv in "${parts[@]}"; do name=${kv%%=*}; value=${kv#*=}; envargs+=("$name=${value//_/ }"); done
-    env "${envargs[@]}" RT_MI355X_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-60s %.2f Gs/s  kernel %.2f ms' % ('$spec', d['value']/1e9, d['roofline']['kernel_ms']))" || exit 1
+    env "${envargs[@]}" RT_MI355X_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-60s %.2f Gs/s  kernel %.2f ms' % ('$spec', d['value']/1e9, d['roofline']['kernel_ms']))" || exit 1
   done
 done

@@ -68,7 +68,7 @@ public:
     {
         check(rt_set_spheres(mHandle, spheres.data(), static_cast<uint32_t>(spheres.size())), "rt_set_spheres");
     }
-    // false = test every sphere against every ray (the shader's loop); true (default) = scenes of 64
+    // false = test every sphere against every ray (the shader's loop); true (default) = scenes of 24
     // spheres or more go through a bounding-sphere hierarchy with identical results
     void setSceneHierarchy(bool enable) { check(rt_set_scene_hierarchy(mHandle, enable ? 1 : 0), "rt_set_scene_hierarchy"); }
     void renderFrames(uint32_t firstFrame, uint32_t frameCount, void* hipStream = nullptr)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/host_params.json, tests/golden/rng_kat.json and tests/golden/glm_builtins.json.
+"""Generates tests/golden/host_params.json, tests/golden/rng_kat.json, tests/golden/glm_builtins.json and
+tests/golden/caller_camera.json.
 
 host_params.json: GPUSphere / GPUParams bytes printed by oracle/_ref/ref_params_probe, a probe
 linked against the reference's own src/rt/RayTracer.cpp (built by `make -C oracle ref`, only
@@ -21,6 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_params_probe")
 GLM_PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_glm_probe")
+CAMERA_PROBE = os.path.join(ROOT, "oracle", "_ref", "ref_camera_probe")
 
 # name -> probe argv.  "default": create() + setSamplesPerPixel(4) + setAperture(a) as App::run does
 # (src/core/App.cpp:153-156); otherwise: width height aperture vfov focus pos dir through the setters.
@@ -91,6 +93,21 @@ def glm_builtins():
     return out
 
 
+def caller_camera():
+    """The camera arithmetic of the reference's frame loop (src/core/App.cpp:180-183, :299-362) on a scripted
+    event sequence, evaluated by oracle/_ref/ref_camera_probe with the reference's vendored GLM: per step the
+    events and the resulting camPos, camDir, yaw, pitch as hex words."""
+    out = {"init": None, "steps": []}
+    for line in subprocess.check_output([CAMERA_PROBE], text=True).splitlines():
+        parts = line.split()
+        if parts[0] == "init":
+            out["init"] = parts[1:]
+        else:
+            out["steps"].append({"dx": float(parts[1]), "dy": float(parts[2]), "keys": "" if parts[3] == "-" else parts[3],
+                                 "dt": float(parts[4]), "state": parts[6:]})
+    return out
+
+
 def main():
     if not os.path.exists(PROBE) or not os.path.exists(GLM_PROBE):
         sys.exit("build oracle/_ref first: make -C oracle ref (needs /root/reference)")
@@ -102,6 +119,9 @@ def main():
     vectors = glm_builtins()
     with open(os.path.join(HERE, "glm_builtins.json"), "w") as f:
         json.dump(vectors, f, separators=(",", ":"))
+    if os.path.exists(CAMERA_PROBE):
+        with open(os.path.join(HERE, "caller_camera.json"), "w") as f:
+            json.dump(caller_camera(), f, indent=1)
     print("wrote host_params.json (%d cases), rng_kat.json and glm_builtins.json (%d vectors)" % (len(params), len(vectors)))
 
 

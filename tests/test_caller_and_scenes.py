@@ -79,3 +79,26 @@ def test_scene_files_round_trip(pkg, tmp_path):
     with pytest.raises(ValueError):
         open(str(tmp_path / "bad.spheres"), "wb").write(b"\0" * 50)
         pkg.load_scene(str(tmp_path / "bad.spheres"))
+
+
+def test_camera_arithmetic_matches_the_reference_glm(pkg, golden_dir):
+    """tests/golden/caller_camera.json holds the reference's own camera arithmetic (src/core/App.cpp:180-183,
+    :299-362) evaluated with its vendored GLM on a scripted sequence of mouse deltas and key presses;
+    FrameLoop must reproduce position, direction, yaw and pitch bit for bit after every step."""
+    import json
+    import os
+    fixture = json.load(open(os.path.join(golden_dir, "caller_camera.json")))
+    rec = Recorder(pkg)
+    loop = pkg.FrameLoop(rec)
+
+    def state():
+        vals = list(loop.cam_pos) + list(loop.cam_dir) + [loop.yaw, loop.pitch]
+        return ["%08x" % int(np.float32(v).view(np.uint32)) for v in vals]
+
+    assert state() == fixture["init"]
+    names = {"W": "W", "S": "S", "A": "A", "D": "D", "U": "SPACE", "P": "SHIFT"}
+    for i, ev in enumerate(fixture["steps"]):
+        loop.step(dt=ev["dt"], mouse=(ev["dx"], ev["dy"]), keys={names[k] for k in ev["keys"]})
+        assert state() == ev["state"], "step %d" % i
+        if ev["keys"] or ev["dx"] or ev["dy"]:
+            assert loop.rendered[-1] == 0      # any camera change restarts the accumulation (:364-368)

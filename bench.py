@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU code path (process group, collective, resolve) even with one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--watchdog", type=int, default=900,
+                    help="seconds after which a rank that is still running prints its Python stacks and exits (0 = off)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
@@ -203,6 +205,10 @@ def main():
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)   # a hung collective must not hang the whole job
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

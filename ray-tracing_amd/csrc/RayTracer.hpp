@@ -75,6 +75,27 @@ public:
     {
         check(rt_render_frames(mHandle, firstFrame, frameCount, hipStream), "rt_render_frames");
     }
+    // Shards for one GPU of several: a row band and/or every frameStride-th frame; every stripeStride-th stripe of
+    // stripeRows rows (rank r of G: stripeFirst = r, stripeStride = G).
+    void renderShard(uint32_t firstFrame, uint32_t frameCount, uint32_t frameStride, uint32_t rowBegin, uint32_t rowEnd,
+                     bool writeOutput = true, void* hipStream = nullptr)
+    {
+        check(rt_render_shard(mHandle, firstFrame, frameCount, frameStride, rowBegin, rowEnd, writeOutput ? 1 : 0, hipStream),
+              "rt_render_shard");
+    }
+    void renderStripes(uint32_t firstFrame, uint32_t frameCount, uint32_t frameStride, uint32_t stripeRows, uint32_t stripeFirst,
+                       uint32_t stripeStride, bool writeOutput = true, void* hipStream = nullptr)
+    {
+        check(rt_render_stripes(mHandle, firstFrame, frameCount, frameStride, stripeRows, stripeFirst, stripeStride,
+                                writeOutput ? 1 : 0, hipStream), "rt_render_stripes");
+    }
+    // renderFrames for callers that must not allocate device memory (work buffers in the library's static device array).
+    void renderFramesStatic(uint32_t firstFrame, uint32_t frameCount, void* hipStream = nullptr)
+    {
+        check(rt_render_frames_static(mHandle, firstFrame, frameCount, hipStream), "rt_render_frames_static");
+    }
+    // Consecutive single-frame render() calls overlap on the GPU by default; false keeps every launch on the caller's stream.
+    void setFrameOverlap(bool enable) { check(rt_set_frame_overlap(mHandle, enable ? 1 : 0), "rt_set_frame_overlap"); }
     GPUParams params(uint32_t frameIndex) const
     {
         GPUParams p{};

@@ -44,6 +44,8 @@ struct rt_tracer {
     bool rng_capture = false;
     float4* partial = nullptr;        // per-frame sums of a multi-frame launch: [frames][height*width]
     size_t partial_bytes = 0;
+    float4* partial2 = nullptr;       // the same for the second slot of overlapping small multi-frame launches
+    size_t partial2_bytes = 0;
     uint32_t* stats = nullptr;        // diagnostic builds only
     rt::SphereTree tree;              // hierarchy over `spheres` (empty for small or out-of-range scenes)
     bool use_tree = true;
@@ -277,6 +279,7 @@ void free_images(rt_tracer* h)
     if (h->output) { (void)hipFree(h->output); h->output = nullptr; }
     if (h->rng_state) { (void)hipFree(h->rng_state); h->rng_state = nullptr; }
     if (h->partial) { (void)hipFree(h->partial); h->partial = nullptr; h->partial_bytes = 0; }
+    if (h->partial2) { (void)hipFree(h->partial2); h->partial2 = nullptr; h->partial2_bytes = 0; }
     if (h->pipe_partial) { (void)hipFree(h->pipe_partial); h->pipe_partial = nullptr; }
     h->pipe_used[0] = h->pipe_used[1] = false;
 }
@@ -585,49 +588,71 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         }
     }
 
+    // Launches may run beside their predecessor (see rt_tracer::overlap_frames): single frames always,
+    // launches of several frames when they are small enough for the drain phase to matter (fewer than
+    // 16 rounds of units: the shards of an image split over several GPUs, say).  Large launches stay on
+    // the caller's stream.  Not while the final RNG words are captured: two launches in flight would both
+    // store theirs.
+    const uint64_t launch_rows = rows.stripe_rows != 0 ? static_cast<uint64_t>(rows.n_stripes) * rows.stripe_rows
+                                                       : rows.row_end - rows.row_begin;
+    const bool small_launch = launch_rows * h->width * n_frames / 512u < rt::resident_wave_slots() * 16u;
+    const bool overlap = !static_scratch && h->overlap_frames && !h->rng_capture && h->stats == nullptr &&
+                         h->pipe_partial != nullptr && (n_frames == 1 || small_launch);
+
     // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
     // accumulator in frame order afterwards; the frames of one call are split into groups so that
     // this image stays within a budget: 16 GiB (a 64-frame batch at 3840x2160 is 8.5 GB and should
     // stay one launch on a 288 GB device), at most a quarter of the memory that is free when the
-    // buffer has to grow, or what RT_PARTIAL_BYTES says.
+    // buffer has to grow, or what RT_PARTIAL_BYTES says.  Overlapping launches alternate between two
+    // such images.
     if (n_frames > 1 && !static_scratch) {
-        size_t budget = static_cast<size_t>(16) << 30;
-        if (const char* e = std::getenv("RT_PARTIAL_BYTES")) {
-            budget = static_cast<size_t>(std::strtoull(e, nullptr, 10));
-        }
-        if (static_cast<size_t>(n_frames) * frame_bytes > h->partial_bytes) {
-            size_t free_bytes = 0, total_bytes = 0;
-            if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
-                budget = std::min(budget, std::max(h->partial_bytes, (free_bytes + h->partial_bytes) / 4));
-            } else {
-                (void)hipGetLastError();
+        auto ensure = [&](float4*& buffer, size_t& bytes) -> int {
+            size_t budget = static_cast<size_t>(16) << 30;
+            if (const char* e = std::getenv("RT_PARTIAL_BYTES")) {
+                budget = static_cast<size_t>(std::strtoull(e, nullptr, 10));
             }
-        }
-        const size_t fit = std::max<size_t>(2, budget / frame_bytes);
-        group = static_cast<uint32_t>(std::min<size_t>(n_frames, fit));
-        if (static_cast<size_t>(group) * frame_bytes > h->partial_bytes) {
-            // kernels of earlier calls may still be reading the old buffer, whatever stream they are on
-            RT_HIP_TRY(h, hipDeviceSynchronize());
-            if (h->partial) {
-                (void)hipFree(h->partial);
-                h->partial = nullptr;
-                h->partial_bytes = 0;
-            }
-            // an allocation that does not fit is retried with half the frames, down to two
-            for (;;) {
-                const size_t need = static_cast<size_t>(group) * frame_bytes;
-                const hipError_t e = device_malloc(reinterpret_cast<void**>(&h->partial), need);
-                if (e == hipSuccess) {
-                    h->partial_bytes = need;
-                    break;
+            if (static_cast<size_t>(group) * frame_bytes > bytes) {
+                size_t free_bytes = 0, total_bytes = 0;
+                if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+                    budget = std::min(budget, std::max(bytes, (free_bytes + bytes) / 4));
+                } else {
+                    (void)hipGetLastError();
                 }
-                h->partial = nullptr;
-                if (e != hipErrorOutOfMemory || group <= 2) {
-                    return fail_hip(h, e, "hipMalloc(per-frame sums)", __FILE__, __LINE__);
-                }
-                (void)hipGetLastError();
-                group = std::max(2u, group / 2u);
             }
+            const size_t fit = std::max<size_t>(2, budget / frame_bytes);
+            group = static_cast<uint32_t>(std::min<size_t>(group, fit));
+            if (static_cast<size_t>(group) * frame_bytes > bytes) {
+                // kernels of earlier calls may still be reading the old buffer, whatever stream they are on
+                RT_HIP_TRY(h, hipDeviceSynchronize());
+                if (buffer) {
+                    (void)hipFree(buffer);
+                    buffer = nullptr;
+                    bytes = 0;
+                }
+                // an allocation that does not fit is retried with half the frames, down to two
+                for (;;) {
+                    const size_t need = static_cast<size_t>(group) * frame_bytes;
+                    const hipError_t e = device_malloc(reinterpret_cast<void**>(&buffer), need);
+                    if (e == hipSuccess) {
+                        bytes = need;
+                        break;
+                    }
+                    buffer = nullptr;
+                    if (e != hipErrorOutOfMemory || group <= 2) {
+                        return fail_hip(h, e, "hipMalloc(per-frame sums)", __FILE__, __LINE__);
+                    }
+                    (void)hipGetLastError();
+                    group = std::max(2u, group / 2u);
+                }
+            }
+            return RT_OK;
+        };
+        int rc = ensure(h->partial, h->partial_bytes);
+        if (rc == RT_OK && overlap) {
+            rc = ensure(h->partial2, h->partial2_bytes); // may shrink `group` further; the first buffer is then larger than needed
+        }
+        if (rc != RT_OK) {
+            return rc;
         }
         partial = h->partial;
     }
@@ -659,9 +684,6 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         }
     }
 
-    // (not while the final RNG words are captured: two launches in flight would both store theirs)
-    const bool overlap = n_frames == 1 && !static_scratch && h->overlap_frames && !h->rng_capture && h->stats == nullptr &&
-                         h->pipe_partial != nullptr;
     for (uint32_t done = 0; done < n_frames; done += group) {
         const uint32_t count = std::min(group, n_frames - done);
         const uint32_t first = first_frame + done * frame_stride;
@@ -703,15 +725,16 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
 
         const uint32_t slot = static_cast<uint32_t>(h->launches % rt_tracer::kTimedLaunches);
         if (overlap) {
-            // this frame's samples are summed per pixel into the call's slot on one of the library's two
-            // streams (nothing there touches the accumulator, so it can run beside the previous call's
-            // launch), and added to the accumulator on the caller's stream: prev + sum, as :333-335 do
+            // this launch's samples are summed per pixel and frame into the call's slot on one of the library's
+            // two streams (nothing there touches the accumulator, so it can run beside the previous call's
+            // launch), and added to the accumulator on the caller's stream in frame order: prev + sum, as
+            // :333-335 do
             const uint32_t p = static_cast<uint32_t>(h->pipe_calls++ & 1u);
             hipStream_t side = h->pipe_stream[p];
             if (h->pipe_used[p]) {
                 RT_HIP_TRY(h, hipStreamWaitEvent(side, h->pipe_free[p], 0)); // the slot's previous sums have been folded
             }
-            args.partial = h->pipe_partial + static_cast<size_t>(p) * image_pixels;
+            args.partial = count == 1 ? h->pipe_partial + static_cast<size_t>(p) * image_pixels : (p == 0 ? h->partial : h->partial2);
             args.output = nullptr;
             args.unit_counter = tree ? h->d_unit_counter + 16u * (1u + p) : nullptr;
             RT_HIP_TRY(h, hipEventRecord(h->ev_start[slot], side));
@@ -720,9 +743,10 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             ++h->launches;
             RT_HIP_TRY(h, hipEventRecord(h->pipe_traced[p], side));
             RT_HIP_TRY(h, hipStreamWaitEvent(stream, h->pipe_traced[p], 0));
-            const float sample_count = static_cast<float>((first + 1u) * h->samples_per_pixel); // :337
-            RT_HIP_TRY(h, rt::launch_fold(h->accum, args.partial, write_output ? h->output : nullptr, h->width, h->height,
-                                          rows, 1, sample_count, stream));
+            // (frame + 1u) * spp wraps in uint32 before the conversion, raytrace.comp.glsl:337
+            const float sample_count = static_cast<float>((first + (count - 1) * frame_stride + 1u) * h->samples_per_pixel);
+            RT_HIP_TRY(h, rt::launch_fold(h->accum, args.partial, (write_output && last_group) ? h->output : nullptr, h->width,
+                                          h->height, rows, count, sample_count, stream));
             RT_HIP_TRY(h, hipEventRecord(h->pipe_free[p], stream));
             h->pipe_used[p] = true;
             continue;

@@ -1187,6 +1187,15 @@ uint64_t resident_blocks(size_t lds, uint32_t waves_per_block)
     return static_cast<uint64_t>(cus) * std::min(by_lds, by_waves);
 }
 
+} // namespace
+
+uint64_t resident_wave_slots()
+{
+    return resident_blocks(0, 1);
+}
+
+namespace {
+
 template <int MODE, int BLOCK, int PERSISTENT>
 void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStream_t stream)
 {
@@ -1248,7 +1257,7 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
             // Measured on the benchmark: the whole image 29.9 / 30.4 / 31.3 ms with units of 512 / 256 /
             // 128 items, the eight stripe shards of it together 41.8 / 36.2 / 34.5 ms.
             const uint64_t items = (uint64_t)args.width * rows * args.n_frames;
-            const uint64_t slots = resident_blocks(0, 1) * 16u;
+            const uint64_t slots = resident_wave_slots() * 16u;
             while (target_items > 128u && items / target_items < slots) {
                 target_items >>= 1;
             }

@@ -70,6 +70,8 @@ constexpr size_t kStaticScratchBytes = kStaticScratchHeader + (static_cast<size_
 // per device.
 hipError_t static_scratch(int device, void** ptr, size_t* bytes);
 
+// Waves the current device holds at a time (32 per compute unit).
+uint64_t resident_wave_slots();
 size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds);
 hipError_t launch_trace(const TraceArgs& args, hipStream_t stream);
 // Rows a launch covers: a contiguous band, or every stripe_stride-th stripe of stripe_rows rows.

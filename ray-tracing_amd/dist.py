@@ -135,7 +135,13 @@ def reduce_frame_split(accum, out=None, group=None, packed=None):
         out.copy_(accum)
     if packed is not None:
         packed.record()
-    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of several ranks on one GPU: gloo's own device path hangs on a side stream here
+        host = out.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(host)
+    else:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     out[..., 3] = 1.0
     return out
 

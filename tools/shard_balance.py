@@ -51,6 +51,15 @@ def main():
         out[mode + "_wall_ms_all_shards_back_to_back"] = wall
         out[mode] = {"shard_ms": [round(m, 4) for m in ms], "sum_ms": sum(ms), "max_ms": max(ms),
                      "speedup_if_parallel": whole / max(ms), "imbalance_max_over_mean": max(ms) / (sum(ms) / world)}
+    # the same shards queued back to back with the library's launch overlap on: what a rank's consecutive steps cost
+    t.set_frame_overlap(True)
+    for rep in range(3):
+        t.synchronize()
+        t0 = time.perf_counter()
+        for r in range(world):
+            t.render_stripes(0, frames, 1, stripe_rows, r, world, write_output=False)
+        t.synchronize()
+        out["stripes_wall_ms_all_shards_overlapped"] = (time.perf_counter() - t0) * 1e3
     print(json.dumps(out, indent=1))
     t.destroy()
 

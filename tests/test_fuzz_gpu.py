@@ -49,6 +49,10 @@ def _case(seed, specials=False):
         "frames": int(rng.choice([1, 2, 3, 7, 40])),
         "pos": (rng.normal(size=3) * rng.choice([2.0, 15.0, 80.0])).astype(np.float32),
         "focus": float(10.0 ** rng.uniform(-1.0, 2.0)),
+        # how the frames are submitted: one launch, one call per frame (consecutive launches overlap on the
+        # library's two streams), or as the interleaved stripe shards of several ranks
+        "pattern": str(rng.choice(["batch", "batch", "calls", "stripes"])),
+        "ranks": int(rng.integers(1, 6)), "stripe_rows": int(rng.choice([1, 2, 3, 4, 8, 16])),
     }
 
 
@@ -74,10 +78,17 @@ def _run_case(pkg, oracle, c):
     if not np.any(direction != 0.0):
         direction = np.array([0.0, 0.0, -1.0], dtype=np.float32)
     t.set_camera(c["pos"].tolist(), direction.tolist(), c["focus"])
-    t.enable_rng_capture(True)
-    t.render_frames(0, c["frames"])
     ref = oracle_frames(oracle, t, c["scene"], range(c["frames"]), want_rng=True)
-    assert same(t.read_rng_state(), ref["rng"])
+    if c["pattern"] == "batch":
+        t.enable_rng_capture(True)
+        t.render_frames(0, c["frames"])
+        assert same(t.read_rng_state(), ref["rng"])
+    elif c["pattern"] == "calls":
+        for f in range(c["frames"]):
+            t.render(f)
+    else:
+        for rank in range(c["ranks"]):
+            t.render_stripes(0, c["frames"], 1, c["stripe_rows"], rank, c["ranks"])
     assert same(t.read_accum(), ref["accum"])
     assert same(t.read_output(), ref["output"])
     t.destroy()

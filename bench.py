@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_LDS_GBPS = 78643.2        # LDS: 256 CU x 128 B/clk x 2.4 GHz
 
 WORKLOADS = {
     # the configuration the metric is quoted on
@@ -60,6 +61,15 @@ def load_flops_per_sample(key):
     with open(path) as f:
         rec = json.load(f).get(key)
     return rec["flops_per_sample"] if rec else None
+
+
+def load_hierarchy_bytes(key):
+    """LDS bytes per path sample of a workload traced through the bounding-sphere hierarchy (node visits counted by
+    the diagnostic build x 32 bytes per visit), or None."""
+    path = os.path.join(ROOT, "profiles", "flops_per_sample.json")
+    with open(path) as f:
+        rec = json.load(f).get(key) or {}
+    return (rec.get("hierarchy") or {}).get("lds_bytes_per_sample")
 
 
 def load_measured_traffic():
@@ -366,7 +376,21 @@ def main():
                        "parallelism": how,
                        "samples_per_step": samples_per_step},
         }
-        if flops_per_sample is not None:
+        lds_bytes = load_hierarchy_bytes(wl["flops_key"])
+        if lds_bytes is not None:
+            # The hierarchy kernel skips 99 % of the sphere tests the shader's loop makes, so the FLOP count "as
+            # written" says nothing about it (it would come out above the peak).  What bounds the walk is LDS: every
+            # node visit is a dependent 32-byte read at a per-lane address.
+            achieved = lds_bytes * launch_samples / avg_kernel_s / 1e9
+            result["roofline"] = {
+                "bound": "lds", "achieved": achieved, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": achieved / PEAK_LDS_GBPS,
+                "traffic": None, "kernel_ms": avg_kernel_s * 1e3, "lds_bytes_per_sample": lds_bytes,
+                "flops_per_sample_as_written": flops_per_sample,
+                "note": "hierarchy walk: achieved = node visits per sample (diagnostic build) x 32 B x samples per launch / "
+                        "HIP-event kernel time; peak = 256 CU x 128 B/clk x 2.4 GHz of LDS bandwidth; the walk is bound by the "
+                        "LATENCY of those dependent reads at 3 waves/SIMD (one 1024-thread workgroup per CU holds the tree), "
+                        "which is why the fraction is low; HBM traffic is negligible"}
+        elif flops_per_sample is not None:
             achieved = flops_per_sample * launch_samples / avg_kernel_s / 1e12
             result["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",

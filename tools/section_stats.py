@@ -30,6 +30,8 @@ def main():
     assert n == len(SECTIONS), (n, len(SECTIONS))
     big = os.environ.get("RT_STATS_SCENE") == "synthetic4096"
     width, height = (960, 540) if big else (1920, 1080)
+    if os.environ.get("RT_STATS_SIZE"):
+        width, height = [int(v) for v in os.environ["RT_STATS_SIZE"].split()]
     t = pkg.RayTracer().create(width, height, device_id=0)
     t.set_samples_per_pixel(16)
     t.set_max_depth(50 if big else 8)
@@ -61,6 +63,11 @@ def main():
         print("  %-20s %6.1f %%   %8.1f cycles/iteration" % (name, 100.0 * c / tot, c / iters))
     out["_phases"] = dict(zip(phases, [int(c) for c in cyc]))
     print("wave iterations per wave-sample: %.3f (ideal = segments per sample: 1.946 for the default scene)" % (iters / (samples / 64.0)))
+    if big:
+        # every visit of a hierarchy node reads 32 bytes of LDS: the two possible successors are fetched while the node is tested
+        visits = out["node"]["lane_execs"] / samples
+        print("hierarchy: %.1f node visits per sample, %.0f bytes of LDS per sample at 32 bytes per visit" % (visits, 32.0 * visits))
+        out["_hierarchy"] = {"node_visits_per_sample": visits, "lds_bytes_per_sample": 32.0 * visits}
     json.dump({"frames": frames, "samples": samples, "sections": out}, open(os.path.join(ROOT, "gpurun_out", "section_stats.json"), "w"), indent=1)
     t.destroy()
 

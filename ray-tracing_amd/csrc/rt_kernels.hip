@@ -1205,6 +1205,9 @@ void launch_trace_as(const TraceArgs& args, uint64_t units, size_t lds, hipStrea
     typedef NoStats StatsPolicy;
 #endif
     const uint32_t waves_per_block = BLOCK / 64;
+    if (const char* e = std::getenv("RT_LDS_PAD")) {
+        lds += (size_t)std::max(0, std::atoi(e)); // experiment: caps the resident workgroups per CU
+    }
     uint64_t blocks = (units + waves_per_block - 1) / waves_per_block;
     if (PERSISTENT != kOneUnit) {
         // no more workgroups than the device holds at a time

@@ -762,6 +762,12 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             const float sample_count = static_cast<float>((last_frame + 1u) * h->samples_per_pixel);
             RT_HIP_TRY(h, rt::launch_fold(h->accum, partial, (write_output && last_group) ? h->output : nullptr,
                                           h->width, h->height, rows, count, sample_count, stream));
+            if (!static_scratch) {
+                // `partial` is also slot 0 of the overlapping launches: one that follows on the library's own
+                // stream must not write it before this fold has read it
+                RT_HIP_TRY(h, hipEventRecord(h->pipe_free[0], stream));
+                h->pipe_used[0] = true;
+            }
         }
     }
     return RT_OK;

@@ -495,3 +495,25 @@ def test_overlapped_single_frame_calls(pkg, oracle, scene_size):
     assert same(a.read_output(), ref["output"])
     a.destroy()
     b.destroy()
+
+
+def test_large_batch_then_small_overlapped_batches_share_a_buffer(pkg, oracle):
+    """A large multi-frame launch (caller's stream) followed at once by small multi-frame launches (traced on the
+    library's own streams into the same per-frame-sum buffer): the small ones must wait for the large one's fold."""
+    w, h = 1920, 1080
+    scene = pkg.default_scene()
+    t = make_tracer(pkg, w, h, 1, 4, 0.0)
+    ref = make_tracer(pkg, w, h, 1, 4, 0.0)
+    ref.set_frame_overlap(False)
+    for tr in (t, ref):
+        tr.render_frames(0, 24)                    # 50 M items: large, not overlapped
+        for k in range(6):
+            tr.render_shard(24 + 2 * k, 2, 1, 0, 64)   # 245 K items each: small, overlapped when allowed
+        tr.render_frames(36, 24)
+    assert same(t.read_accum(), ref.read_accum())
+    assert same(t.read_output(), ref.read_output())
+    band = oracle_frames(oracle, t, scene, [0], row_begin=0, row_end=8)
+    t.render_shard(0, 1, 1, 0, 8)
+    assert same(t.read_accum()[0:8], band["accum"][0:8])
+    t.destroy()
+    ref.destroy()

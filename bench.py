@@ -405,7 +405,9 @@ def main():
                                   "frac": None, "traffic": None, "kernel_ms": avg_kernel_s * 1e3,
                                   "note": "no algorithmic FLOP count recorded for this workload (tools/count_flops.py)"}
         if distributed:
-            result["rank_kernel_ms"] = {"min": kernel_spread[0], "max": kernel_spread[1]}
+            result["rank_kernel_ms"] = {"min": kernel_spread[0], "max": kernel_spread[1],
+                                        "note": "HIP-event time of each rank's trace launches; shard launches are small, so the "
+                                                "library lets consecutive ones overlap and each time includes the shared part"}
         elif args.workload == "c2" and not args.no_extras:
             result["other_call_patterns"] = other_call_patterns(pkg, device_index, stream)
         if baseline is not None:

@@ -190,7 +190,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--mode", choices=["tiles", "frames"], default="tiles", help="how N > 1 ranks share a step")
@@ -264,6 +264,11 @@ def main():
         tracer.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
     stream = torch.cuda.current_stream(device)
     tracer.set_stream(stream.cuda_stream)
+    if not distributed:
+        # one launch at a time on one GPU, so that the HIP-event time of a launch (the roofline figure) is that
+        # launch's alone; the benchmark's own launch is too large to be overlapped anyway, the single-frame and
+        # small-batch workloads (c4, c5) would be
+        tracer.set_frame_overlap(False)
 
     stripe_rows = args.stripe_rows or (16 if height >= 4000 else 4)
     accum = rtdist.accum_tensor(tracer, device) if distributed else None

@@ -117,7 +117,7 @@ int rt_set_scene_hierarchy(rt_handle h, int enable);
  * leaf, bits 17..30 sphere index of a leaf, bits 0..16 byte offset = 16 * index
  * of the node to continue with when the node's test fails).  *n_nodes receives
  * the node count, 0 when the scene has no hierarchy.  Either array may be NULL.
- * A hierarchy of more than 7900 nodes is not kept in this format: asking for
+ * A hierarchy of more than 7850 nodes is not kept in this format: asking for
  * its words fails (geom and *n_nodes are still delivered); use the call below. */
 int rt_get_scene_hierarchy(rt_handle h, float *geom, uint32_t *word, uint32_t cap, uint32_t *n_nodes);
 /* The same hierarchy with whole words, for trees of any size (scenes of up to

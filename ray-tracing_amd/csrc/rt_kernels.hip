@@ -5,7 +5,7 @@
 //
 // Work decomposition.  The unit of independent work is an ITEM = one (pixel, frame) pair: its
 // `spp` samples share one random stream (:310-331) whose draw count per sample is data dependent,
-// so they stay on one lane, in order.  A wave owns a UNIT = a small pixel tile (2x4 to 8x8, chosen
+// so they stay on one lane, in order.  A wave owns a UNIT = a small pixel tile (2x4 to 8x16, chosen
 // per launch) x a chunk of up to `frames_per_unit` frames.  Lanes pull items from that pool with a
 // ballot/prefix count (no atomics, no LDS): a lane that finishes its item takes the next one, so
 // all 64 lanes stay busy until the pool drains, whatever the path lengths were.
@@ -414,8 +414,8 @@ struct Unit {
     uint32_t rel_begin;      // first frame of the chunk, relative to first_frame
     uint32_t n_items;
 };
-constexpr uint32_t kUnitWords = 80; // offset of the unit description in a wave's table
-constexpr uint32_t kWaveTableWords = 88;
+constexpr uint32_t kUnitWords = 96; // offset of the unit description in a wave's table
+constexpr uint32_t kWaveTableWords = 104;
 
 // The kernel's argument struct as it lies in the kernel-argument segment (it is the only argument).
 // Blocks that run rarely read what they need from there instead of keeping it in scalar registers
@@ -454,7 +454,7 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
     const uint32_t tile = unit - chunk * A->n_tiles;
     const uint32_t tile_y = tile / A->tiles_x;
     const uint32_t tile_x = tile - tile_y * A->tiles_x;
-    // the pixel tile of a unit is 2^tile_w_log2 x 2^tile_h_log2, at most 8 x 8
+    // the pixel tile of a unit is 2^tile_w_log2 x 2^tile_h_log2, at most 16 x 16
     u.x0 = tile_x << A->tile_w_log2;
     u.tile_w = min(1u << A->tile_w_log2, A->width - u.x0);
     const uint32_t rel_row = tile_y << A->tile_h_log2;
@@ -475,11 +475,11 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
     const uint32_t rel_count = min(A->frames_per_unit, A->n_frames - u.rel_begin);
     u.n_items = u.tile_pixels * rel_count;
     const uint32_t lane = threadIdx.x & 63u;
-    if (lane < 16u) {
-        hash_tab[lane] = hash1(lane < 8u ? u.x0 + lane : u.y0 + lane - 8u);
+    if (lane < 32u) {
+        hash_tab[lane] = hash1(lane < 16u ? u.x0 + lane : u.y0 + lane - 16u);
     }
     if (lane < rel_count) {
-        hash_tab[16u + lane] = hash1(A->first_frame + (u.rel_begin + lane) * A->frame_stride);
+        hash_tab[32u + lane] = hash1(A->first_frame + (u.rel_begin + lane) * A->frame_stride);
     }
     if (lane == 0u) {
         hash_tab[kUnitWords + 0u] = u.x0;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
             texel = py * args_in_memory()->width + px;
             fpx = (float)(int32_t)px;
             fpy_flipped = res_y_minus_1 - (float)(int32_t)py;
-            rng = hash_tab[lx] ^ hash_tab[8u + ly] ^ hash_tab[16u + frame_in_chunk]; // :310-311
+            rng = hash_tab[lx] ^ hash_tab[16u + ly] ^ hash_tab[32u + frame_in_chunk]; // :310-311
             samples_left = spp;
             has_item = true;
         }
@@ -1160,7 +1160,7 @@ size_t trace_lds_bytes(uint32_t sphere_count, bool* mat_in_lds)
     if (mat_in_lds != nullptr) {
         *mat_in_lds = full;
     }
-    // scene records + 80 hash words for each of up to 8 waves
+    // scene records + the hash tables of up to 8 waves
     return (size_t)sphere_count * (full ? 64u : 16u) + 8u * kWaveTableWords * 4u;
 }
 
@@ -1241,7 +1241,7 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         args.frames_per_unit = 1;
     }
     args.frames_per_unit = std::min(std::min(args.frames_per_unit, 64u), args.n_frames);
-    if (args.tile_w_log2 > 3u || args.tile_h_log2 > 3u) {
+    if (args.tile_w_log2 > 4u || args.tile_h_log2 > 4u) {
         // Not chosen by the caller: a unit pools about 512 items, from as many frames and as few
         // pixels as the launch allows (between 2 x 4 and 8 x 8 pixels).  Measured on the benchmark
         // (64 frames): 8 x 8 pixels x 16 frames 55.0 Gsamples/s, 8 x 8 x 8 56.6, 4 x 4 x 16 57.2,
@@ -1268,7 +1268,9 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         if (args.unit_items != 0u) {
             target_items = args.unit_items;
         }
-        uint32_t log2_pixels = 6;
+        // (up to 8 x 16 pixels where the host asks for it: single-frame launches that overlap their neighbours,
+        // whose waves otherwise hold one item per lane and wait for the slowest)
+        uint32_t log2_pixels = args.max_tile_log2 >= 3u && args.max_tile_log2 <= 8u ? args.max_tile_log2 : 6u;
         while (log2_pixels > 3u && (args.frames_per_unit << log2_pixels) > target_items) {
             --log2_pixels;
         }
@@ -1281,7 +1283,7 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     // a tile must not straddle two stripes: its height divides stripe_rows (wider instead, up to 8)
     while (args.stripe_rows != 0u && args.stripe_rows % (1u << args.tile_h_log2) != 0u) {
         --args.tile_h_log2;
-        if (args.tile_w_log2 < 3u) {
+        if (args.tile_w_log2 < 4u) {
             ++args.tile_w_log2;
         }
     }

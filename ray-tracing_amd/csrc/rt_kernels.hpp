@@ -53,9 +53,10 @@ struct TraceArgs {
     uint32_t n_frames;
     uint32_t frame_stride;
     uint32_t frames_per_unit;     // frames of one tile a wave pools together (1..64)
-    uint32_t tile_w_log2;         // pixel tile of a unit, 2^w x 2^h with w, h <= 3; anything larger = let launch_trace choose
+    uint32_t tile_w_log2;         // pixel tile of a unit, 2^w x 2^h with w, h <= 4; anything larger = let launch_trace choose
     uint32_t tile_h_log2;
     uint32_t unit_items;          // items a unit should pool (0 = launch_trace's default)
+    uint32_t max_tile_log2;       // log2 of the largest pixel tile launch_trace may choose (0 = 6, i.e. 8 x 8)
     // filled in by launch_trace
     uint32_t tiles_x;
     uint32_t n_tiles;

@@ -51,7 +51,7 @@ constexpr uint32_t kTreeIndexShift = 17;
 // Most nodes a tree in the packed format may have: offsets are 17 bits of bytes / 16 (8191), and
 // 20 bytes per node plus the hash tables of sixteen waves have to fit the 160 KiB of LDS of a
 // compute unit.
-constexpr uint32_t kTreeMaxNodes = 7900;
+constexpr uint32_t kTreeMaxNodes = 7850;
 
 // Largest scene a hierarchy is built for (byte offsets of nodes stay below 2^32 with room to spare).
 constexpr uint32_t kTreeMaxSpheres = 1u << 20;

@@ -72,7 +72,7 @@ def test_structure(pkg, name):
              "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
     t = _host(pkg, scene)
     geom, word = t.get_scene_hierarchy()
-    assert 0 < len(word) <= 7900
+    assert 0 < len(word) <= 7850
     _check_structure(scene, geom, word)
     # the same scene gives the same hierarchy
     t2 = _host(pkg, scene)
@@ -453,7 +453,7 @@ def test_links_agree_with_packed_words_and_cover_large_scenes(pkg):
     big = pkg.synthetic_scene(9000)
     t.set_spheres(big)
     geom, link, sphere = t.get_scene_hierarchy_links()
-    assert len(link) > 7900                      # beyond the packed format
+    assert len(link) > 7850                      # beyond the packed format
     _check_links(big, geom, link, sphere)
     with pytest.raises(RuntimeError, match="too large for packed"):
         t.get_scene_hierarchy()
@@ -507,7 +507,7 @@ def test_largest_tree_kept_in_lds(pkg):
     scene = pkg.synthetic_scene(count)
     t = _host(pkg, scene)
     nodes = len(t.get_scene_hierarchy_links()[1])
-    while nodes > 7900:
+    while nodes > 7850:
         count -= 50
         scene = pkg.synthetic_scene(count)
         t.set_spheres(scene)

@@ -517,3 +517,39 @@ def test_large_batch_then_small_overlapped_batches_share_a_buffer(pkg, oracle):
     assert same(t.read_accum()[0:8], band["accum"][0:8])
     t.destroy()
     ref.destroy()
+
+
+@pytest.mark.parametrize("w,h", [(65536, 1), (1, 8192), (16384, 3), (7, 4099)])
+def test_extreme_extents(pkg, oracle, w, h):
+    """The widest image the interface accepts, one-pixel-wide columns, and sizes that are no multiple of any
+    tile: every texel once, with the oracle's bits."""
+    t = make_tracer(pkg, w, h, 1, 4, 0.05)
+    t.enable_rng_capture(True)
+    t.render_frames(0, 2)
+    ref = oracle_frames(oracle, t, pkg.default_scene(), [0, 1], want_rng=True)
+    assert same(t.read_rng_state(), ref["rng"])
+    assert same(t.read_accum(), ref["accum"])
+    assert same(t.read_output(), ref["output"])
+    t.destroy()
+
+
+@pytest.mark.parametrize("frame,spp", [(0xFFFFFFFF, 3), (0x55555555, 3), (0x7FFFFFFF, 2), (0xFFFFFFFE, 5)])
+def test_frame_counter_wraps_like_the_shader(pkg, oracle, frame, spp):
+    """(frame + 1) * spp is evaluated in 32-bit unsigned arithmetic by the shader (raytrace.comp.glsl:337): frame
+    indices near 2^32 make the divisor wrap (to 0 for frame 0xFFFFFFFF: the image is then inf/NaN through the tone
+    map), and the seed hash takes the frame index as it is."""
+    w, h = 48, 20
+    for overlap in (True, False):
+        t = make_tracer(pkg, w, h, spp, 4, 0.05)
+        t.set_frame_overlap(overlap)
+        t.render(frame)
+        ref = oracle_frames(oracle, t, pkg.default_scene(), [frame])
+        assert same(t.read_accum(), ref["accum"])
+        assert same(t.read_output(), ref["output"])
+        # a batch that runs across the wrap: frames frame, frame + 1 (mod 2^32)
+        t.reset_accumulation()
+        t.render_frames(frame, 2)
+        ref = oracle_frames(oracle, t, pkg.default_scene(), [frame, (frame + 1) & 0xFFFFFFFF])
+        assert same(t.read_accum(), ref["accum"])
+        assert same(t.read_output(), ref["output"])
+        t.destroy()

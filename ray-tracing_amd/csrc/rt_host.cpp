@@ -861,9 +861,15 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
                 // stream and run behind it instead of beside it.  Streams of another priority get their
                 // queues from a pool of their own.
                 int least = 0, greatest = 0;
-                RT_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+                    (void)hipGetLastError();
+                    greatest = 0;
+                }
                 const int priority = std::getenv("RT_PIPE_NORMAL_PRIORITY") != nullptr ? 0 : greatest;
-                RT_HIP_TRY(h, hipStreamCreateWithPriority(&h->pipe_stream[i], hipStreamNonBlocking, priority));
+                if (hipStreamCreateWithPriority(&h->pipe_stream[i], hipStreamNonBlocking, priority) != hipSuccess) {
+                    (void)hipGetLastError(); // no priorities here: an ordinary stream still overlaps when a queue is free
+                    RT_HIP_TRY(h, hipStreamCreateWithFlags(&h->pipe_stream[i], hipStreamNonBlocking));
+                }
                 RT_HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_traced[i], hipEventDisableTiming));
                 RT_HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_free[i], hipEventDisableTiming));
             }

@@ -98,11 +98,31 @@ ABI = {
 _lib = None
 
 
+def _preload_pytorch_hip_runtime():
+    """PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  A process can only use one
+    copy: whichever is loaded first finds the GPU, the other reports none.  Where PyTorch is installed its copy
+    is therefore loaded before this library (without importing torch), so that the tracer and a later
+    `import torch` share it whatever the import order.  RT_MI355X_SYSTEM_HIP=1 skips this."""
+    if os.environ.get("RT_MI355X_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        candidate = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(candidate):
+            ctypes.CDLL(candidate, mode=ctypes.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load_library(path=None):
     """Loads librt_mi355x.so and declares every entry point.  Raises if it is missing."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    _preload_pytorch_hip_runtime()
     # RT_MI355X_LIB selects another build of the same library (A/B timing of kernel variants)
     p = path or os.environ.get("RT_MI355X_LIB") or LIB_PATH
     if not os.path.exists(p):

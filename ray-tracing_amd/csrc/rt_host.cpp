@@ -81,6 +81,12 @@ struct rt_tracer {
     float4* pipe_partial = nullptr;   // two images of per-frame sums
     uint64_t pipe_calls = 0;
 
+    // Recorded on the caller's stream at the end of every render call: what a scene change or a growing
+    // work buffer waits for before it frees memory that the handle's kernels read, instead of idling
+    // the whole device (other handles, copies and collectives on the same GPU keep running).
+    hipEvent_t last_render = nullptr;
+    bool rendered = false;
+
     // HIP event pairs around the most recent trace launches (a ring), for rt_kernel_ms
     static constexpr uint32_t kTimedLaunches = 64;
     hipEvent_t ev_start[kTimedLaunches] = {};
@@ -107,6 +113,29 @@ int fail_hip(rt_tracer* h, hipError_t e, const char* expr, const char* file, int
     (void)hipGetLastError(); // clear the sticky per-thread error
     return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP;
 }
+
+// Blocks until the kernels of the handle's render calls so far have finished.
+hipError_t wait_for_renders(rt_tracer* h)
+{
+    if (!h->rendered || h->last_render == nullptr) {
+        return hipSuccess;
+    }
+    return hipEventSynchronize(h->last_render);
+}
+
+// Records rt_tracer::last_render when a render call returns, whichever way it returns.
+struct RenderMark {
+    rt_tracer* h;
+    hipStream_t stream;
+    ~RenderMark()
+    {
+        if (h->last_render != nullptr && hipEventRecord(h->last_render, stream) == hipSuccess) {
+            h->rendered = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+};
 
 int fail_arg(rt_tracer* h, const char* what)
 {
@@ -400,9 +429,8 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
         }
     }
 
-    // the previous scene may still be read by a kernel in flight, on whatever stream (vkDeviceWaitIdle
-    // in the reference's resize/destroy; scene changes are rare)
-    RT_HIP_TRY(h, hipDeviceSynchronize());
+    // the previous scene may still be read by one of the handle's kernels in flight
+    RT_HIP_TRY(h, wait_for_renders(h));
     Staged d_spheres, d_tree_geom, d_tree_word, d_loop_geom, d_counter;
     auto body = [&]() -> int {
         RT_HIP_TRY(h, d_spheres.take(h->d_spheres, h->d_sphere_capacity, n, n * sizeof(rt_gpu_sphere)));
@@ -560,6 +588,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     }
     DeviceScope scope(h->device);
     RT_HIP_TRY(h, scope.status());
+    const RenderMark mark{ h, stream }; // destroyed before `scope`, so with the handle's device still current
 
     const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
     const size_t frame_bytes = image_pixels * sizeof(float4);
@@ -622,8 +651,8 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             const size_t fit = std::max<size_t>(2, budget / frame_bytes);
             group = static_cast<uint32_t>(std::min<size_t>(group, fit));
             if (static_cast<size_t>(group) * frame_bytes > bytes) {
-                // kernels of earlier calls may still be reading the old buffer, whatever stream they are on
-                RT_HIP_TRY(h, hipDeviceSynchronize());
+                // kernels of earlier calls may still be reading the old buffer
+                RT_HIP_TRY(h, wait_for_renders(h));
                 if (buffer) {
                     (void)hipFree(buffer);
                     buffer = nullptr;
@@ -873,6 +902,7 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
                 RT_HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_traced[i], hipEventDisableTiming));
                 RT_HIP_TRY(h, hipEventCreateWithFlags(&h->pipe_free[i], hipEventDisableTiming));
             }
+            RT_HIP_TRY(h, hipEventCreateWithFlags(&h->last_render, hipEventDisableTiming));
             h->overlap_frames = std::getenv("RT_NO_FRAME_OVERLAP") == nullptr;
             // the library's set-up per device: the address of the file-scope scratch array that
             // rt_render_frames_static works in (each device holds its own copy)
@@ -966,6 +996,7 @@ int rt_destroy(rt_handle h)
             if (h->pipe_free[i]) { (void)hipEventDestroy(h->pipe_free[i]); }
             if (h->pipe_stream[i]) { (void)hipStreamDestroy(h->pipe_stream[i]); }
         }
+        if (h->last_render) { (void)hipEventDestroy(h->last_render); }
         (void)hipGetLastError();
     }
     delete h;

@@ -519,6 +519,37 @@ def test_large_batch_then_small_overlapped_batches_share_a_buffer(pkg, oracle):
     ref.destroy()
 
 
+def test_scene_change_and_buffer_growth_behind_renders_in_flight(pkg, oracle):
+    """rt_set_spheres and a growing per-frame-sum buffer wait for the handle's own kernels (an event on the
+    caller's stream), not for the whole device: a scene written over the one a launch in flight still reads,
+    or a freed buffer a fold still reads, would show in the image."""
+    import torch
+    w, h = 1920, 1080
+    scene_a = pkg.default_scene()
+    scene_b = scene_a.copy()
+    scene_b[1:, 1] += 1.5                               # every small sphere lifted: most pixels change
+    stream = torch.cuda.Stream()
+    t = make_tracer(pkg, w, h, 2, 8, 0.05)
+    t.set_stream(stream.cuda_stream)
+    calm = make_tracer(pkg, w, h, 2, 8, 0.05)
+    t.render_frames(0, 2)                            # small buffer of per-frame sums
+    t.render_frames(2, 30)                           # grows it while the first call's fold may still run
+    t.set_spheres(scene_b)                           # same count: written into the buffer the launch reads
+    got = t.read_accum()
+    calm.render_frames(0, 2)
+    calm.synchronize()
+    calm.render_frames(2, 30)
+    calm.synchronize()
+    assert same(got, calm.read_accum())
+    band = oracle_frames(oracle, calm, scene_a, range(32), row_begin=536, row_end=540)
+    assert same(got[536:540], band["accum"][536:540])
+    t.render_frames(0, 2)                            # the raised flag clears; scene B from here on
+    band = oracle_frames(oracle, t, scene_b, [0, 1], row_begin=536, row_end=544)
+    assert same(t.read_accum()[536:544], band["accum"][536:544])
+    t.destroy()
+    calm.destroy()
+
+
 @pytest.mark.parametrize("w,h", [(65536, 1), (1, 8192), (16384, 3), (7, 4099)])
 def test_extreme_extents(pkg, oracle, w, h):
     """The widest image the interface accepts, one-pixel-wide columns, and sizes that are no multiple of any

@@ -120,7 +120,12 @@ hipError_t wait_for_renders(rt_tracer* h)
     if (!h->rendered || h->last_render == nullptr) {
         return hipSuccess;
     }
-    return hipEventSynchronize(h->last_render);
+    if (hipEventSynchronize(h->last_render) == hipSuccess) {
+        return hipSuccess;
+    }
+    // e.g. the event was recorded into a stream capture: it cannot be waited for, so wait for everything
+    (void)hipGetLastError();
+    return hipDeviceSynchronize();
 }
 
 // Records rt_tracer::last_render when a render call returns, whichever way it returns.

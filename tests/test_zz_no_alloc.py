@@ -68,3 +68,37 @@ def test_static_scratch_rejects_images_it_cannot_hold(pkg):
     assert same(u.read_accum(), v.read_accum())
     for x in (t, r, u, v):
         x.destroy()
+
+
+@pytest.mark.parametrize("scene_size", [5, 200])
+def test_static_scratch_entry_point_inside_a_stream_capture(pkg, scene_size):
+    """What the entry point is for: a stream capture forbids allocation and synchronisation.  One call is
+    captured into a HIP graph (nothing runs during the capture), the graph is replayed twice, and each replay
+    leaves the image an ordinary rt_render_frames call leaves; afterwards the handle works outside the graph,
+    a scene change included (which waits for the handle's kernels and cannot wait for a captured event)."""
+    import torch
+    w, h, frames = 320, 200, 5
+    scene = pkg.default_scene() if scene_size == 5 else pkg.synthetic_scene(scene_size)
+    ref = make_tracer(pkg, w, h, 2, 6, 0.05, scene=scene)
+    ref.render_frames(0, frames)
+    want_accum, want_output = ref.read_accum(), ref.read_output()
+    stream = torch.cuda.Stream()
+    t = make_tracer(pkg, w, h, 2, 6, 0.05, scene=scene)
+    t.set_stream(stream.cuda_stream)
+    marker = np.full((h, w, 4), 7.0, dtype=np.float32)
+    t.write_accum(marker)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        t.render_frames_static(0, frames)
+    assert same(t.read_accum(), marker)             # captured, not run
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert same(t.read_accum(), want_accum)
+        assert same(t.read_output(), want_output)
+    t.set_spheres(scene)
+    t.render_frames(0, frames)
+    assert same(t.read_accum(), want_accum)
+    del graph
+    t.destroy()
+    ref.destroy()

@@ -102,6 +102,19 @@ public:
         check(rt_get_params(mHandle, frameIndex, &p), "rt_get_params");
         return p;
     }
+    // Blocking copies of the accumulator (float4 per pixel) and of the rgba8 image to the host, row 0 = top.
+    std::vector<float> readAccum(Extent extent, void* hipStream = nullptr) const
+    {
+        std::vector<float> image(static_cast<size_t>(extent.width) * extent.height * 4u);
+        check(rt_read_accum(mHandle, image.data(), image.size() * sizeof(float), hipStream), "rt_read_accum");
+        return image;
+    }
+    std::vector<uint8_t> readOutput(Extent extent, void* hipStream = nullptr) const
+    {
+        std::vector<uint8_t> image(static_cast<size_t>(extent.width) * extent.height * 4u);
+        check(rt_read_output(mHandle, image.data(), image.size(), hipStream), "rt_read_output");
+        return image;
+    }
     void* accumDevicePtr() const { return rt_accum_device_ptr(mHandle); }
     void* outputDevicePtr() const { return rt_output_device_ptr(mHandle); }
     void synchronize(void* hipStream = nullptr) { check(rt_synchronize(mHandle, hipStream), "rt_synchronize"); }

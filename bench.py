@@ -205,6 +205,10 @@ def main():
                     help="seconds after which a rank that is still running prints its Python stacks and exits (0 = off)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="timing rehearsal on one GPU: this process does rank 0's part of a job of that many ranks, with "
+                         "the collective replaced by device copies of the same size (not a measurement of several GPUs)")
+    ap.add_argument("--comm-priority", type=int, default=0, help="priority of the stream the collective runs on")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -226,7 +230,11 @@ def main():
     if args.gpus != world:
         sys.exit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     wl = WORKLOADS[args.workload]
-    distributed = world > 1 or args.force_distributed
+    rehearse = (args.rehearse_world, 0) if args.rehearse_world > 1 else None
+    if rehearse and world != 1:
+        sys.exit("--rehearse-world is for a single process")
+    distributed = world > 1 or args.force_distributed or rehearse is not None
+    split_world, split_rank = rehearse if rehearse else (world, rank)
     if args.scaling == "weak" and args.mode != "frames":
         sys.exit("--scaling weak needs --mode frames (a fixed image cannot grow with the ranks)")
 
@@ -245,7 +253,7 @@ def main():
     device_index = 0 if args.same_device else local_rank
     torch.cuda.set_device(device_index)
     device = torch.device("cuda", device_index)
-    if distributed:
+    if distributed and not rehearse:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -276,9 +284,11 @@ def main():
     # image: the accumulator is only read while a rank's shard is packed, so the next step's render starts as
     # soon as the packing is done and runs beside the collective.
     image = torch.empty_like(accum) if distributed else None
-    comm = torch.cuda.Stream(device) if distributed else None
+    # (at the priority of the library's own trace streams by default: behind a stream of higher priority the
+    # small kernels of the collective would wait for the trace launch to drain)
+    comm = torch.cuda.Stream(device, priority=args.comm_priority) if distributed else None
     packed = None
-    frames_per_step = frames * world if args.scaling == "weak" else frames
+    frames_per_step = frames * split_world if args.scaling == "weak" else frames
 
     def step(index):
         nonlocal packed
@@ -290,12 +300,12 @@ def main():
             stream.wait_event(packed)      # the previous step's shard has been read out of the accumulator
         if args.mode == "tiles":
             # rank r: stripes r, r + world, ... of every frame of the step
-            tracer.render_stripes(base, frames, 1, stripe_rows, rank, world, write_output=False)
+            tracer.render_stripes(base, frames, 1, stripe_rows, split_rank, split_world, write_output=False)
         else:
             # rank r: frames base + r, base + r + world, ... of the whole image
-            count = len(range(rank, frames_per_step, world))
+            count = len(range(split_rank, frames_per_step, split_world))
             if count:
-                tracer.render_shard(base + rank, count, world, 0, height, write_output=False)
+                tracer.render_shard(base + split_rank, count, split_world, 0, height, write_output=False)
         rendered = torch.cuda.Event()
         rendered.record(stream)
         packed = torch.cuda.Event()
@@ -303,16 +313,18 @@ def main():
             comm.wait_event(rendered)
             tracer.set_stream(comm.cuda_stream)
             if args.mode == "tiles":
-                rtdist.gather_stripes(accum, stripe_rows, out=image, packed=packed)   # the image is put together
+                rtdist.gather_stripes(accum, stripe_rows, out=image, packed=packed, rehearse=rehearse)  # the image is put together
             else:
-                rtdist.reduce_frame_split(accum, out=image, packed=packed)            # the partial sums are added
+                rtdist.reduce_frame_split(accum, out=image, packed=packed, rehearse=rehearse)           # the partial sums are added
             tracer.resolve_output_from(image.data_ptr(), (base + frames_per_step) * spp)
             tracer.set_stream(stream.cuda_stream)
 
     def fence():
         if distributed:
             comm.synchronize()
-            if args.backend == "nccl":
+            if rehearse:
+                pass
+            elif args.backend == "nccl":
                 dist.barrier(device_ids=[device_index])
             else:
                 torch.cuda.synchronize(device)
@@ -332,7 +344,9 @@ def main():
     kernel_ms = [tracer.kernel_ms(i) for i in range(min(args.steps, 64))]
     kernel_ms = [k for k in kernel_ms if k >= 0.0]
 
-    if distributed:
+    if rehearse:
+        kernel_spread = (sum(kernel_ms) / max(1, len(kernel_ms)),) * 2
+    elif distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -354,17 +368,22 @@ def main():
             launch_samples = samples_per_step
         elif args.mode == "tiles":
             my_rows = sum(min(height, (s + 1) * stripe_rows) - s * stripe_rows
-                          for s in rtdist.stripes_of_rank(height, stripe_rows, world, rank))
+                          for s in rtdist.stripes_of_rank(height, stripe_rows, split_world, split_rank))
             launch_samples = width * my_rows * spp * frames
         else:
-            launch_samples = width * height * spp * len(range(rank, frames_per_step, world))
+            launch_samples = width * height * spp * len(range(split_rank, frames_per_step, split_world))
         if distributed:
-            how = ("interleaved %d-row stripes x%d + RCCL all-gather of the accumulator" % (stripe_rows, world)
-                   if args.mode == "tiles" else "frame-index split x%d + RCCL sum all-reduce of the accumulator" % world)
+            how = ("interleaved %d-row stripes x%d + RCCL all-gather of the accumulator" % (stripe_rows, split_world)
+                   if args.mode == "tiles" else "frame-index split x%d + RCCL sum all-reduce of the accumulator" % split_world)
+            if rehearse:
+                how = ("REHEARSAL ON ONE GPU, not a measurement of %d GPUs: rank 0's part of [%s], the collective replaced by "
+                       "device copies of the same size; value = what %d ranks would reach if each took as long"
+                       % (split_world, how, split_world))
         else:
             how = "1 GPU"
         result = {
-            "metric": "path samples/sec at 1080p depth 8",
+            "metric": ("REHEARSAL of %d ranks on one GPU, not a measurement: " % split_world if rehearse else "") +
+                      "path samples/sec at 1080p depth 8",
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
@@ -421,7 +440,7 @@ def main():
         json_out.flush()
 
     tracer.destroy()
-    if distributed:
+    if distributed and not rehearse:
         dist.destroy_process_group()
 
 

@@ -79,7 +79,7 @@ def _all_gather_into(recv, send, group):
         dist.all_gather_into_tensor(recv, send, group=group)
 
 
-def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None):
+def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None, rehearse=None):
     """accum: (H, W, C) tensor whose stripes rank, rank + G, ... (stripes of stripe_rows rows; the last
     one may be cut short by the image) are valid on this rank.  After the call `out` (default: accum
     itself) holds the complete image on every rank.  One collective: each rank packs its stripes into a
@@ -88,9 +88,16 @@ def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None):
 
     With a separate `out`, accum is only read, and only while the shard is packed: `packed`, a
     torch.cuda.Event, is recorded right after that, so that a caller who runs the gather on a side stream
-    can let the next render into accum start while the collective is still in flight."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    can let the next render into accum start while the collective is still in flight.
+
+    rehearse = (world, rank): one process on one GPU stands in for that rank of a larger job, without a
+    process group; the collective is replaced by device copies of this rank's buffer into every rank's
+    place (the same bytes land in the same buffers, the image is not a valid one).  For timing rehearsals."""
+    if rehearse is not None:
+        world, rank = rehearse
+    else:
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
     height, width, channels = accum.shape
     target = accum if out is None else out
     n_stripes = stripe_count(height, stripe_rows)
@@ -114,7 +121,11 @@ def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None):
         packed.record()
     # (the collective wants the ranks' contributions concatenated along the first dimension)
     flat = accum.new_empty((world * slots, stripe_rows, width, channels))
-    _all_gather_into(flat, send, group)
+    if rehearse is not None:
+        for r in range(world):
+            flat[r * slots:(r + 1) * slots].copy_(send)
+    else:
+        _all_gather_into(flat, send, group)
     recv = flat.view(world, slots, stripe_rows, width, channels)
     if full_rounds:
         target[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels).copy_(
@@ -125,7 +136,7 @@ def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None):
     return target
 
 
-def reduce_frame_split(accum, out=None, group=None, packed=None):
+def reduce_frame_split(accum, out=None, group=None, packed=None, rehearse=None):
     """Sums the per-rank accumulators of a frame split.  accum: (H, W, 4) float32.  Returns the
     reduced image (in `out` if given, else in place) with alpha restored to 1.  With a separate `out`,
     accum is only read by the copy that starts the call; `packed` (a torch.cuda.Event) is recorded after it."""
@@ -135,7 +146,11 @@ def reduce_frame_split(accum, out=None, group=None, packed=None):
         out.copy_(accum)
     if packed is not None:
         packed.record()
-    if out.is_cuda and dist.get_backend(group) == "gloo":
+    if rehearse is not None:
+        # one process standing in for a rank of a larger job (timing rehearsal): device traffic of the
+        # order of a reduce-scatter + all-gather of the image instead of the collective
+        out.add_(out.clone())
+    elif out.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal of several ranks on one GPU: gloo's own device path hangs on a side stream here
         host = out.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -739,13 +739,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         if (kRegenQuorum != 0u && !TREE) {
             const unsigned long long done_mask = wave_ballot(path_done);
             const unsigned long long in_loop = wave_ballot(true);
-#ifdef RT_REGEN_RELAX
-            // experiment: the quorum shrinks with the lanes still in the loop (a wave that is draining its pool)
-            const uint32_t quorum = min(kRegenQuorum, ((uint32_t)__popcll(in_loop) + RT_REGEN_RELAX - 1u) / RT_REGEN_RELAX);
-            regen = path_done && ((uint32_t)__popcll(done_mask) >= quorum || done_mask == in_loop);
-#else
             regen = path_done && ((uint32_t)__popcll(done_mask) >= kRegenQuorum || done_mask == in_loop);
-#endif
         }
         const bool need_item = regen && samples_left == 0u;
         const bool write_out = need_item && has_item;

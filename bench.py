@@ -421,6 +421,13 @@ def main():
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                 "traffic": load_measured_traffic() if args.workload == "c2" and not distributed else None,
                 "kernel_ms": avg_kernel_s * 1e3, "flops_per_sample": flops_per_sample,
+                "ceilings": {"unit": "TFLOP/s", "fma_every_slot": PEAK_FP32_VALU_TFLOPS,
+                             "one_flop_per_slot": PEAK_FP32_VALU_TFLOPS / 2,
+                             "one_flop_per_slot_at_measured_issue_rate": PEAK_FP32_VALU_TFLOPS / 2 * 2.0 / 2.45,
+                             "note": "results must equal the shader's operation by operation, so no multiply-add is fused and a "
+                                     "slot carries one flop; packed FP32 issues at twice the cycles of the plain instruction here "
+                                     "(tools/ubench/valu_rates.hip) and adds nothing; 2.45 SIMD-cycles per VALU instruction is the "
+                                     "PMC figure of this kernel with the VALU saturated (profiles/r2f/pmc_summary.json)"},
                 "note": "FP32 VALU-bound kernel (no MFMA; HBM traffic is the 16 B per-frame sum per pixel per frame, "
                         "i.e. well under 100 GB/s); achieved = algorithmic FLOP per launch / HIP-event kernel time of "
                         "rank 0's launch; traffic = bytes per launch from the committed rocprofv3 PMC passes"}

@@ -105,8 +105,8 @@ def host_threads():
 
 def cpu_baseline(pkg, wl, budget_s=10.0):
     """The CPU oracle (a port of the reference shader) timed on this machine's host cores: as many frames
-    of the benchmark workload as fit the time budget, and BASELINE.json's own CPU-runnable case (1280x720,
-    1 spp, depth 8) next to it."""
+    of the benchmark workload as fit the time budget, and the configuration quoted for a CPU run of the reference
+    (1280x720, 1 spp, depth 8) next to it."""
     from oracle import pyoracle
     threads, machine = host_threads()
     scene = pkg.default_scene()

@@ -32,15 +32,34 @@ def _random_scene(rng, count):
 SPECIALS = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-30, 1e-42, 3.0e38, 2.0 ** 20, 2.0 ** 21, 2.0 ** -20, 2.0 ** -21]
 
 
-def _case(seed, specials=False):
+BIG_COUNTS = [401, 1024, 1025, 1500, 2500, 4096, 4097, 5600, 6000, 9000]
+
+
+def _case(seed, specials=False, big=False):
+    """big: scenes of 401 to 9000 spheres on small images -- whole records in LDS up to 1024 spheres, geometry
+    only up to 4096, global memory beyond, the hierarchy in LDS up to about 5600 spheres and in global memory
+    beyond, each with the hierarchy on or off."""
     rng = np.random.default_rng(seed)
-    count = int(rng.choice([1, 2, 5, 17, 23, 24, 25, 63, 64, 65, 150, 400]))
+    count = int(rng.choice(BIG_COUNTS if big else [1, 2, 5, 17, 23, 24, 25, 63, 64, 65, 150, 400]))
     scene = _random_scene(rng, count)
     if specials:
         # out-of-range and non-finite values in geometry and material fields: the shader's arithmetic is
         # defined for them too (NaN compares false, so e.g. a NaN root is accepted by :125-131)
         for _ in range(int(rng.integers(1, 4))):
             scene[int(rng.integers(0, count)), int(rng.choice([0, 1, 2, 3, 4, 9, 10]))] = rng.choice(SPECIALS)
+    if big:
+        return {
+            "scene": scene,
+            "w": int(rng.integers(3, 28)), "h": int(rng.integers(2, 18)),
+            "spp": int(rng.choice([1, 2])), "depth": int(rng.choice([1, 3, 12, 50])),
+            "aperture": float(rng.choice([0.0, 0.05, 0.8])), "fov": float(rng.uniform(5.0, 120.0)),
+            "frames": int(rng.choice([1, 2, 3])),
+            "pos": (rng.normal(size=3) * rng.choice([2.0, 15.0, 80.0])).astype(np.float32),
+            "focus": float(10.0 ** rng.uniform(-1.0, 2.0)),
+            "pattern": str(rng.choice(["batch", "calls", "stripes"])),
+            "ranks": int(rng.integers(1, 4)), "stripe_rows": int(rng.choice([1, 2, 4, 8])),
+            "hierarchy": bool(rng.random() < 0.6),
+        }
     return {
         "scene": scene,
         "w": int(rng.integers(3, 70)), "h": int(rng.integers(2, 50)),
@@ -66,6 +85,11 @@ def test_special_values_match_the_oracle(pkg, oracle, seed):
     _run_case(pkg, oracle, _case(5000 + seed, specials=True))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_large_random_scenes_match_the_oracle(pkg, oracle, seed):
+    _run_case(pkg, oracle, _case(9000 + seed, specials=(seed % 4 == 3), big=True))
+
+
 def _run_case(pkg, oracle, c):
     t = pkg.RayTracer().create(c["w"], c["h"], device_id=0)
     t.set_samples_per_pixel(c["spp"])
@@ -73,6 +97,8 @@ def _run_case(pkg, oracle, c):
     t.set_aperture(c["aperture"])
     t.set_fov(c["fov"])
     t.set_spheres(c["scene"])
+    if not c.get("hierarchy", True):
+        t.set_scene_hierarchy(False)
     target = c["scene"][len(c["scene"]) // 2, 0:3]
     direction = target - c["pos"]
     if not np.any(direction != 0.0):

@@ -519,6 +519,33 @@ def test_large_batch_then_small_overlapped_batches_share_a_buffer(pkg, oracle):
     ref.destroy()
 
 
+@pytest.mark.parametrize("caller_priority", [0, -1])
+def test_overlapped_calls_beside_application_streams(pkg, oracle, caller_priority):
+    """The library traces overlapped calls on two streams of the highest priority.  An application that
+    keeps high-priority streams of its own busy, and whose own stream is of normal or of high priority, gets
+    the same image and no stall (the suite's time limit ends a hang)."""
+    import torch
+    w, h, frames = 320, 180, 24
+    scene = pkg.default_scene()
+    caller = torch.cuda.Stream(priority=caller_priority)
+    busy = [torch.cuda.Stream(priority=-1) for _ in range(4)]
+    buffers = [torch.zeros(1 << 18, device="cuda") for _ in busy]
+    t = make_tracer(pkg, w, h, 3, 8, 0.05)
+    t.set_stream(caller.cuda_stream)
+    for f in range(frames):
+        for s, b in zip(busy, buffers):
+            with torch.cuda.stream(s):
+                b.add_(1.0)
+        t.render(f)
+    t.synchronize()
+    torch.cuda.synchronize()
+    ref = oracle_frames(oracle, t, scene, range(frames))
+    assert same(t.read_accum(), ref["accum"])
+    assert same(t.read_output(), ref["output"])
+    assert all(float(b[0]) == frames for b in buffers)
+    t.destroy()
+
+
 def test_scene_change_and_buffer_growth_behind_renders_in_flight(pkg, oracle):
     """rt_set_spheres and a growing per-frame-sum buffer wait for the handle's own kernels (an event on the
     caller's stream), not for the whole device: a scene written over the one a launch in flight still reads,

@@ -153,7 +153,13 @@ int rt_render(rt_handle h, uint32_t frame_index, void *stream);
  * launch on the caller's stream (for callers that capture the stream into a HIP
  * graph).  The reference serialises its dispatches with a semaphore
  * (src/core/App.cpp:163-168) because each one reads the accumulator; here only
- * the short fold does. */
+ * the short fold does.  Two consequences for the caller: an overlapped call
+ * may wait on the host until the call before the previous one has been folded
+ * (the library's streams never wait on the device, so that no ring of waiting
+ * streams can form when the runtime lets streams share a hardware queue); and
+ * of several handles on one GPU only one overlaps at a time, the first that
+ * makes such a call, until it is destroyed or has its overlap switched off
+ * while idle (launches of different handles run beside each other anyway). */
 int rt_set_frame_overlap(rt_handle h, int enable);
 
 /* n_frames consecutive rt_render calls (frame_index = first_frame ..

@@ -31,6 +31,10 @@ static_assert(offsetof(rt_gpu_params, frame_sample_depth_count) == 112, "uvec4 s
 static_assert(offsetof(rt_gpu_params, resolution) == 128, "resolution sits at byte 128");
 static_assert(offsetof(rt_gpu_params, inv_resolution) == 144, "invResolution sits at byte 144");
 
+#ifndef RT_PIPE_SLOTS
+#define RT_PIPE_SLOTS 2
+#endif
+
 struct rt_tracer {
     int device = 0;
     uint32_t width = 0;
@@ -74,12 +78,14 @@ struct rt_tracer {
     // sum image of its own, and the sums are folded into the accumulator on the caller's stream, in call
     // order.  The drain phase of one launch then runs next to the start of the following one.
     bool overlap_frames = true;
-    hipStream_t pipe_stream[2] = {};
-    hipEvent_t pipe_traced[2] = {};   // the trace of the slot has finished
-    hipEvent_t pipe_free[2] = {};     // the fold that read the slot has finished
-    bool pipe_used[2] = { false, false };
-    float4* pipe_partial = nullptr;   // two images of per-frame sums
+    static constexpr uint32_t kPipeSlots = RT_PIPE_SLOTS;
+    hipStream_t pipe_stream[kPipeSlots] = {};
+    hipEvent_t pipe_traced[kPipeSlots] = {};   // the trace of the slot has finished
+    hipEvent_t pipe_free[kPipeSlots] = {};     // the fold that read the slot has finished
+    bool pipe_used[kPipeSlots] = {};
+    float4* pipe_partial = nullptr;   // kPipeSlots images of per-frame sums
     uint64_t pipe_calls = 0;
+    uint32_t pipe_last_slot = 0;      // slot of the most recent overlapped launch
 
     // Recorded on the caller's stream at the end of every render call: what a scene change or a growing
     // work buffer waits for before it frees memory that the handle's kernels read, instead of idling
@@ -112,6 +118,32 @@ int fail_hip(rt_tracer* h, hipError_t e, const char* expr, const char* file, int
     }
     (void)hipGetLastError(); // clear the sticky per-thread error
     return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP;
+}
+
+// One handle per device overlaps its launches at a time: launches of different handles (on different streams of
+// the application) run beside each other anyway, and the library's extra streams then only add contention
+// (measured with 2 / 3 / 4 tracers rendering single frames on streams of their own: 0.087 / 0.068 / 0.055 ms per
+// frame and tracer with one overlapping handle, 0.092 / 0.081 / 0.087 ms with all of them overlapping).  The first
+// handle to make an overlapped call on a device owns the overlap until it is destroyed, or has it switched off
+// while none of its overlapped launches is in flight.
+constexpr int kMaxOverlapDevices = 64;
+std::atomic<rt_tracer*> g_overlap_owner[kMaxOverlapDevices];
+
+bool claim_overlap(rt_tracer* h)
+{
+    if (h->device < 0 || h->device >= kMaxOverlapDevices) {
+        return false;
+    }
+    rt_tracer* owner = nullptr;
+    return g_overlap_owner[h->device].compare_exchange_strong(owner, h) || owner == h;
+}
+
+void release_overlap(rt_tracer* h)
+{
+    if (h->device >= 0 && h->device < kMaxOverlapDevices) {
+        rt_tracer* owner = h;
+        (void)g_overlap_owner[h->device].compare_exchange_strong(owner, nullptr);
+    }
 }
 
 // Blocks until the kernels of the handle's render calls so far have finished.
@@ -315,7 +347,7 @@ void free_images(rt_tracer* h)
     if (h->partial) { (void)hipFree(h->partial); h->partial = nullptr; h->partial_bytes = 0; }
     if (h->partial2) { (void)hipFree(h->partial2); h->partial2 = nullptr; h->partial2_bytes = 0; }
     if (h->pipe_partial) { (void)hipFree(h->pipe_partial); h->pipe_partial = nullptr; }
-    h->pipe_used[0] = h->pipe_used[1] = false;
+    for (bool& used : h->pipe_used) { used = false; }
 }
 
 // RayTracer::createAccumulationImage, src/rt/RayTracer.cpp:498-527 (+ the output image
@@ -328,7 +360,7 @@ int allocate_images(rt_tracer* h, uint32_t width, uint32_t height, Images& out)
         RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.accum), pixels * sizeof(float4)));
         RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.output), pixels * sizeof(uint32_t)));
         RT_HIP_TRY(h, hipMemset(out.output, 0, pixels * sizeof(uint32_t)));
-        RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.pipe_partial), 2 * pixels * sizeof(float4)));
+        RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.pipe_partial), rt_tracer::kPipeSlots * pixels * sizeof(float4)));
         if (h->rng_capture) {
             RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.rng_state), pixels * sizeof(uint32_t)));
             RT_HIP_TRY(h, hipMemset(out.rng_state, 0, pixels * sizeof(uint32_t)));
@@ -442,7 +474,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
         if (nodes != 0) {
             RT_HIP_TRY(h, d_tree_geom.take(h->d_tree_geom, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * sizeof(float4)));
             RT_HIP_TRY(h, d_tree_word.take(h->d_tree_word, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * 2u * sizeof(uint32_t)));
-            RT_HIP_TRY(h, d_counter.take(h->d_unit_counter, 1, 1, 256));
+            RT_HIP_TRY(h, d_counter.take(h->d_unit_counter, 1, 1, 64u * (1u + rt_tracer::kPipeSlots)));
         }
         if (!loop_geom.empty()) {
             RT_HIP_TRY(h, d_loop_geom.take(h->d_loop_geom, h->d_loop_geom_capacity, n, static_cast<size_t>(n) * sizeof(float4)));
@@ -631,7 +663,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
                                                        : rows.row_end - rows.row_begin;
     const bool small_launch = launch_rows * h->width * n_frames / 512u < rt::resident_wave_slots() * 16u;
     const bool overlap = !static_scratch && h->overlap_frames && !h->rng_capture && h->stats == nullptr &&
-                         h->pipe_partial != nullptr && (n_frames == 1 || small_launch);
+                         h->pipe_partial != nullptr && (n_frames == 1 || small_launch) && claim_overlap(h);
 
     // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
     // accumulator in frame order afterwards; the frames of one call are split into groups so that
@@ -760,7 +792,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             // many waves, a longer drain: 1.0 ms against 0.76 ms for the benchmark's frame); beside a
             // neighbour it is faster (0.53 against 0.55 ms; 0.195 against 0.205 ms at 4 spp).  So it is chosen
             // when the previous call's launch, on the library's other stream, has not finished yet.
-            const uint32_t other = static_cast<uint32_t>((h->pipe_calls & 1u) ^ 1u);
+            const uint32_t other = h->pipe_last_slot;
             bool neighbour_running = false;
             if (h->pipe_used[other]) {
                 const hipError_t q = hipEventQuery(h->pipe_traced[other]);
@@ -784,10 +816,18 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             // two streams (nothing there touches the accumulator, so it can run beside the previous call's
             // launch), and added to the accumulator on the caller's stream in frame order: prev + sum, as
             // :333-335 do
-            const uint32_t p = static_cast<uint32_t>(h->pipe_calls++ & 1u);
+            // (launches of several frames alternate between the two per-frame-sum buffers of the handle)
+            const uint32_t p = static_cast<uint32_t>(h->pipe_calls++ % (count == 1 ? rt_tracer::kPipeSlots : 2u));
+            h->pipe_last_slot = p;
             hipStream_t side = h->pipe_stream[p];
             if (h->pipe_used[p]) {
-                RT_HIP_TRY(h, hipStreamWaitEvent(side, h->pipe_free[p], 0)); // the slot's previous sums have been folded
+                // The slot's previous sums must have been folded.  The HOST waits for that (it is the call before
+                // last, so the launch of the last call keeps the GPU busy meanwhile), not the library's stream:
+                // the library's streams then never wait for anything on the device, and no ring of streams
+                // waiting for each other can form when the runtime lets several streams share a hardware queue
+                // (which it does from the fifth active stream of a process on, and which stalled this
+                // pipeline for good when it still waited on the device).
+                RT_HIP_TRY(h, hipEventSynchronize(h->pipe_free[p]));
             }
             args.partial = count == 1 ? h->pipe_partial + static_cast<size_t>(p) * image_pixels : (p == 0 ? h->partial : h->partial2);
             args.output = nullptr;
@@ -889,7 +929,7 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_start[i]));
                 RT_HIP_TRY(h, hipEventCreate(&h->ev_stop[i]));
             }
-            for (int i = 0; i < 2; ++i) {
+            for (uint32_t i = 0; i < rt_tracer::kPipeSlots; ++i) {
                 // Streams of normal priority share a few hardware queues in turn (four per process by
                 // default), so with other streams alive two of them can land on the queue of the caller's
                 // stream and run behind it instead of beside it.  Streams of another priority get their
@@ -986,6 +1026,7 @@ int rt_destroy(rt_handle h)
     if (h->device >= 0) {
         DeviceScope scope(h->device);
         (void)hipDeviceSynchronize(); // vkDeviceWaitIdle, :238
+        release_overlap(h);
         free_images(h);
         if (h->d_spheres) { (void)hipFree(h->d_spheres); }
         if (h->d_tree_geom) { (void)hipFree(h->d_tree_geom); }
@@ -996,7 +1037,7 @@ int rt_destroy(rt_handle h)
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
             if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }
         }
-        for (int i = 0; i < 2; ++i) {
+        for (uint32_t i = 0; i < rt_tracer::kPipeSlots; ++i) {
             if (h->pipe_traced[i]) { (void)hipEventDestroy(h->pipe_traced[i]); }
             if (h->pipe_free[i]) { (void)hipEventDestroy(h->pipe_free[i]); }
             if (h->pipe_stream[i]) { (void)hipStreamDestroy(h->pipe_stream[i]); }
@@ -1131,6 +1172,20 @@ int rt_set_frame_overlap(rt_handle h, int enable)
         return RT_ERR_BAD_ARGUMENT;
     }
     h->overlap_frames = enable != 0;
+    if (!h->overlap_frames && h->device >= 0) {
+        // another handle may take over once this one's overlapped launches have all been folded
+        DeviceScope scope(h->device);
+        bool idle = scope.status() == hipSuccess;
+        for (uint32_t p = 0; p < rt_tracer::kPipeSlots && idle; ++p) {
+            if (h->pipe_used[p] && hipEventQuery(h->pipe_free[p]) != hipSuccess) {
+                (void)hipGetLastError();
+                idle = false;
+            }
+        }
+        if (idle) {
+            release_overlap(h);
+        }
+    }
     return RT_OK;
 }
 

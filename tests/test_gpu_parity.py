@@ -546,6 +546,61 @@ def test_overlapped_calls_beside_application_streams(pkg, oracle, caller_priorit
     t.destroy()
 
 
+def test_overlapped_calls_survive_stream_and_tracer_changes(pkg, oracle):
+    """Sequences that once stalled the launch overlap for good (the suite's time limit ends a hang): a tracer
+    used on one PyTorch stream and destroyed, then another on a second stream; several tracers at once, each on
+    a stream of its own (one of them overlaps); one tracer whose caller alternates between two streams."""
+    import torch
+    w, h, frames = 256, 144, 20
+    scene = pkg.default_scene()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+
+    def fresh(stream):
+        t = make_tracer(pkg, w, h, 3, 8, 0.05)
+        t.set_stream(stream.cuda_stream)
+        return t
+
+    first = fresh(streams[0])
+    for f in range(frames):
+        first.render(f)
+    want = oracle_frames(oracle, first, scene, range(frames))["accum"]
+    assert same(first.read_accum(), want)
+    first.destroy()
+    second = fresh(streams[1])
+    for f in range(frames):
+        second.render(f)
+    assert same(second.read_accum(), want)
+    second.destroy()
+
+    crowd = [fresh(s) for s in streams]
+    for f in range(frames):
+        for t in crowd:
+            t.render(f)
+    for t in crowd:
+        assert same(t.read_accum(), want)
+    crowd[0].destroy()                   # the overlap passes to whoever asks next
+    for f in range(frames):
+        for t in crowd[1:]:
+            t.render(f)
+    for t in crowd[1:]:
+        assert same(t.read_accum(), want)
+        t.destroy()
+
+    t = fresh(streams[2])
+    previous = None
+    for f in range(frames):
+        s = streams[2 + f % 2]
+        if previous is not None:
+            s.wait_event(previous)       # the application orders its own streams
+        t.set_stream(s.cuda_stream)
+        t.render(f)
+        previous = torch.cuda.Event()
+        previous.record(s)
+    torch.cuda.synchronize()
+    assert same(t.read_accum(), want)
+    t.destroy()
+
+
 def test_scene_change_and_buffer_growth_behind_renders_in_flight(pkg, oracle):
     """rt_set_spheres and a growing per-frame-sum buffer wait for the handle's own kernels (an event on the
     caller's stream), not for the whole device: a scene written over the one a launch in flight still reads,

@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU code path (process group, collective, resolve) even with one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
-    ap.add_argument("--watchdog", type=int, default=900,
+    ap.add_argument("--watchdog", type=int, default=300,
                     help="seconds after which a rank that is still running prints its Python stacks and exits (0 = off)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (with --backend gloo)")
@@ -209,6 +209,9 @@ def main():
                     help="timing rehearsal on one GPU: this process does rank 0's part of a job of that many ranks, with "
                          "the collective replaced by device copies of the same size (not a measurement of several GPUs)")
     ap.add_argument("--comm-priority", type=int, default=0, help="priority of the stream the collective runs on")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed steps rank 0 renders all their frames again on its own GPU and compares the image "
+                         "the ranks put together with it (tiles: bit for bit; frames: relative RMSE)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -280,44 +283,57 @@ def main():
 
     stripe_rows = args.stripe_rows or (16 if height >= 4000 else 4)
     accum = rtdist.accum_tensor(tracer, device) if distributed else None
-    # The collective of a step runs on a side stream into a second image, and the display resolve reads that
-    # image: the accumulator is only read while a rank's shard is packed, so the next step's render starts as
-    # soon as the packing is done and runs beside the collective.
+    # The collective of a step runs on a side stream, and the rendering stream never waits for that stream: the
+    # rank's shard is copied out of the accumulator on the rendering stream itself (into one of two staging
+    # buffers), the side stream waits for that copy, runs the collective, puts the image together in a second
+    # image and resolves it for display, and before a staging buffer is used again the HOST waits for the
+    # collective that read it two steps earlier.  So the next step's render starts right after the copy and runs
+    # beside the collective, and no two streams ever wait for each other (streams that do can stall for good
+    # when the runtime makes them share a hardware queue).
     image = torch.empty_like(accum) if distributed else None
-    # (at the priority of the library's own trace streams by default: behind a stream of higher priority the
-    # small kernels of the collective would wait for the trace launch to drain)
     comm = torch.cuda.Stream(device, priority=args.comm_priority) if distributed else None
-    packed = None
+    staging = [None, None]
+    collected = [None, None]
     frames_per_step = frames * split_world if args.scaling == "weak" else frames
 
     def step(index):
-        nonlocal packed
         base = index * frames_per_step
         if not distributed:
             tracer.render_frames(base, frames)
             return
-        if packed is not None:
-            stream.wait_event(packed)      # the previous step's shard has been read out of the accumulator
+        slot = index % 2
+        if collected[slot] is not None:
+            collected[slot].synchronize()      # host: the collective of two steps ago has read this staging buffer
         if args.mode == "tiles":
             # rank r: stripes r, r + world, ... of every frame of the step
             tracer.render_stripes(base, frames, 1, stripe_rows, split_rank, split_world, write_output=False)
+            if split_world > 1:
+                staging[slot] = rtdist.pack_stripes(accum, stripe_rows, send=staging[slot], rehearse=(split_world, split_rank))
+            else:
+                staging[slot] = accum.clone() if staging[slot] is None else staging[slot].copy_(accum)
         else:
             # rank r: frames base + r, base + r + world, ... of the whole image
             count = len(range(split_rank, frames_per_step, split_world))
             if count:
                 tracer.render_shard(base + split_rank, count, split_world, 0, height, write_output=False)
-        rendered = torch.cuda.Event()
-        rendered.record(stream)
-        packed = torch.cuda.Event()
+            staging[slot] = accum.clone() if staging[slot] is None else staging[slot].copy_(accum)
+        copied = torch.cuda.Event()
+        copied.record(stream)
         with torch.cuda.stream(comm):
-            comm.wait_event(rendered)
+            comm.wait_event(copied)
             tracer.set_stream(comm.cuda_stream)
             if args.mode == "tiles":
-                rtdist.gather_stripes(accum, stripe_rows, out=image, packed=packed, rehearse=rehearse)  # the image is put together
+                if split_world > 1:
+                    rtdist.gather_packed(staging[slot], image, stripe_rows, rehearse=rehearse)   # the image is put together
+                    shown = image
+                else:
+                    shown = staging[slot]
             else:
-                rtdist.reduce_frame_split(accum, out=image, packed=packed, rehearse=rehearse)           # the partial sums are added
-            tracer.resolve_output_from(image.data_ptr(), (base + frames_per_step) * spp)
+                shown = rtdist.reduce_in_place(staging[slot], rehearse=rehearse)                 # the partial sums are added
+            tracer.resolve_output_from(shown.data_ptr(), (base + frames_per_step) * spp)
             tracer.set_stream(stream.cuda_stream)
+            collected[slot] = torch.cuda.Event()
+            collected[slot].record(comm)
 
     def fence():
         if distributed:
@@ -359,6 +375,27 @@ def main():
 
     samples_per_step = width * height * spp * frames_per_step
     value = samples_per_step * args.steps / elapsed
+
+    verified = None
+    if args.verify and distributed and rank == 0 and not rehearse:
+        import numpy as np
+        last = (args.warmup + args.steps - 1) % 2
+        together = (staging[last] if (args.mode == "frames" or split_world == 1) else image).cpu().numpy()
+        whole = pkg.RayTracer().create(width, height, device_id=device_index)
+        whole.set_samples_per_pixel(spp)
+        whole.set_max_depth(wl["depth"])
+        whole.set_aperture(wl["aperture"])
+        if wl["scene"] == "synthetic4096":
+            whole.set_spheres(pkg.synthetic_scene(4096))
+            whole.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
+        whole.render_frames(0, (args.warmup + args.steps) * frames_per_step)
+        alone = whole.read_accum()
+        whole.destroy()
+        if args.mode == "tiles":
+            verified = "bit-identical" if np.array_equal(alone.view(np.uint32), together.view(np.uint32)) else "DIFFERENT"
+        else:
+            rmse = float(np.sqrt(np.mean((alone[..., :3].astype(np.float64) - together[..., :3]) ** 2)))
+            verified = {"rmse_over_mean": rmse / float(alone[..., :3].mean()), "alpha_is_one": bool(np.all(together[..., 3] == 1.0))}
 
     if rank == 0:
         flops_per_sample = load_flops_per_sample(wl["flops_key"])
@@ -441,6 +478,8 @@ def main():
                                                 "library lets consecutive ones overlap and each time includes the shared part"}
         elif args.workload == "c2" and not args.no_extras:
             result["other_call_patterns"] = other_call_patterns(pkg, device_index, stream)
+        if verified is not None:
+            result["verified_against_one_gpu"] = verified
         if baseline is not None:
             result["cpu_baseline"] = baseline
         json_out.write(json.dumps(result) + "\n")

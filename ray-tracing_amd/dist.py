@@ -79,48 +79,46 @@ def _all_gather_into(recv, send, group):
         dist.all_gather_into_tensor(recv, send, group=group)
 
 
-def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None, rehearse=None):
-    """accum: (H, W, C) tensor whose stripes rank, rank + G, ... (stripes of stripe_rows rows; the last
-    one may be cut short by the image) are valid on this rank.  After the call `out` (default: accum
-    itself) holds the complete image on every rank.  One collective: each rank packs its stripes into a
-    (K, stripe_rows, W, C) buffer, K = ceil(stripes / G), and the gathered (G, K, ...) buffer is copied
-    back with ranks and slots swapped -- for the stripes of complete rounds that is a single strided copy.
-
-    With a separate `out`, accum is only read, and only while the shard is packed: `packed`, a
-    torch.cuda.Event, is recorded right after that, so that a caller who runs the gather on a side stream
-    can let the next render into accum start while the collective is still in flight.
-
-    rehearse = (world, rank): one process on one GPU stands in for that rank of a larger job, without a
-    process group; the collective is replaced by device copies of this rank's buffer into every rank's
-    place (the same bytes land in the same buffers, the image is not a valid one).  For timing rehearsals."""
+def _world_rank(group, rehearse):
     if rehearse is not None:
-        world, rank = rehearse
-    else:
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
+        return rehearse
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def pack_stripes(accum, stripe_rows, group=None, send=None, rehearse=None):
+    """Copies this rank's stripes (rank, rank + G, ... of stripes of stripe_rows rows; the last one may be cut
+    short by the image) out of the (H, W, C) image into a (K, stripe_rows, W, C) buffer, K = ceil(stripes / G),
+    on the current stream, and returns the buffer (`send` if given).  After it the image may be written again."""
+    world, rank = _world_rank(group, rehearse)
     height, width, channels = accum.shape
-    target = accum if out is None else out
     n_stripes = stripe_count(height, stripe_rows)
     slots = (n_stripes + world - 1) // world
-    if world == 1:
-        if target is not accum:
-            target.copy_(accum)
-        if packed is not None:
-            packed.record()
-        return target
+    if send is None:
+        send = accum.new_zeros((slots, stripe_rows, width, channels))
+    assert tuple(send.shape) == (slots, stripe_rows, width, channels)
     full_rounds = (height // stripe_rows) // world      # rounds in which every rank owns a complete stripe
     rows_in_rounds = full_rounds * world * stripe_rows
-    send = accum.new_zeros((slots, stripe_rows, width, channels))
     if full_rounds:
         send[:full_rounds].copy_(accum[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels)[:, rank])
     for stripe in range(full_rounds * world, n_stripes):
         if stripe % world == rank:
             rows = accum[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
             send[stripe // world, :rows.shape[0]].copy_(rows)
-    if packed is not None:
-        packed.record()
+    return send
+
+
+def gather_packed(send, out, stripe_rows, group=None, rehearse=None):
+    """The collective half: one all_gather_into_tensor of the ranks' packed stripes and the copy that puts
+    them back in image order into `out` (H, W, C) -- for the stripes of complete rounds a single strided copy.
+    Runs on the current stream and only reads `send`."""
+    world, rank = _world_rank(group, rehearse)
+    height, width, channels = out.shape
+    n_stripes = stripe_count(height, stripe_rows)
+    slots = (n_stripes + world - 1) // world
+    full_rounds = (height // stripe_rows) // world
+    rows_in_rounds = full_rounds * world * stripe_rows
     # (the collective wants the ranks' contributions concatenated along the first dimension)
-    flat = accum.new_empty((world * slots, stripe_rows, width, channels))
+    flat = send.new_empty((world * slots, stripe_rows, width, channels))
     if rehearse is not None:
         for r in range(world):
             flat[r * slots:(r + 1) * slots].copy_(send)
@@ -128,12 +126,58 @@ def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None, rehear
         _all_gather_into(flat, send, group)
     recv = flat.view(world, slots, stripe_rows, width, channels)
     if full_rounds:
-        target[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels).copy_(
+        out[:rows_in_rounds].view(full_rounds, world, stripe_rows, width, channels).copy_(
             recv[:, :full_rounds].permute(1, 0, 2, 3, 4))
     for stripe in range(full_rounds * world, n_stripes):
-        rows = target[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
+        rows = out[stripe * stripe_rows:min(height, (stripe + 1) * stripe_rows)]
         rows.copy_(recv[stripe % world, stripe // world, :rows.shape[0]])
-    return target
+    return out
+
+
+def gather_stripes(accum, stripe_rows, group=None, out=None, packed=None, rehearse=None):
+    """accum: (H, W, C) tensor whose stripes rank, rank + G, ... are valid on this rank.  After the call `out`
+    (default: accum itself) holds the complete image on every rank: pack_stripes, then gather_packed, on the
+    current stream; bit-identical to the image of one GPU.
+
+    With a separate `out`, accum is only read while the shard is packed: `packed`, a torch.cuda.Event, is
+    recorded right after that.  (A caller that pipelines steps should rather pack on the stream that renders
+    and run gather_packed on a side stream, so that the rendering stream never waits for the side stream:
+    two streams that wait for each other can stall for good when the runtime makes them share a hardware
+    queue.  bench.py does that.)
+
+    rehearse = (world, rank): one process on one GPU stands in for that rank of a larger job, without a
+    process group; the collective is replaced by device copies of this rank's buffer into every rank's
+    place (the same bytes land in the same buffers, the image is not a valid one).  For timing rehearsals."""
+    world, rank = _world_rank(group, rehearse)
+    target = accum if out is None else out
+    if world == 1:
+        if target is not accum:
+            target.copy_(accum)
+        if packed is not None:
+            packed.record()
+        return target
+    send = pack_stripes(accum, stripe_rows, group=group, rehearse=rehearse)
+    if packed is not None:
+        packed.record()
+    return gather_packed(send, target, stripe_rows, group=group, rehearse=rehearse)
+
+
+def reduce_in_place(image, group=None, rehearse=None):
+    """The collective half of the frame split: sums the ranks' (H, W, 4) float32 images in place and restores
+    alpha to 1 (the shader stores alpha = 1 every frame, raytrace.comp.glsl:335; a sum gives G)."""
+    if rehearse is not None:
+        # one process standing in for a rank of a larger job (timing rehearsal): device traffic of the
+        # order of a reduce-scatter + all-gather of the image instead of the collective
+        image.add_(image.clone())
+    elif image.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of several ranks on one GPU: gloo's own device path hangs on a side stream here
+        host = image.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        image.copy_(host)
+    else:
+        dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    image[..., 3] = 1.0
+    return image
 
 
 def reduce_frame_split(accum, out=None, group=None, packed=None, rehearse=None):
@@ -146,19 +190,7 @@ def reduce_frame_split(accum, out=None, group=None, packed=None, rehearse=None):
         out.copy_(accum)
     if packed is not None:
         packed.record()
-    if rehearse is not None:
-        # one process standing in for a rank of a larger job (timing rehearsal): device traffic of the
-        # order of a reduce-scatter + all-gather of the image instead of the collective
-        out.add_(out.clone())
-    elif out.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsal of several ranks on one GPU: gloo's own device path hangs on a side stream here
-        host = out.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        out.copy_(host)
-    else:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-    out[..., 3] = 1.0
-    return out
+    return reduce_in_place(out, group=group, rehearse=rehearse)
 
 
 class DeviceImage:

@@ -146,11 +146,31 @@ def test_bench_starts_its_own_ranks(tmp_path):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--same-device", "--backend", "gloo"], env=env, capture_output=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--same-device", "--backend", "gloo", "--verify"], env=env, capture_output=True, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
     assert rec["config"]["samples_per_step"] == 1920 * 1080 * 16 * 64
+    # the image the two ranks put together over four pipelined steps is the one a single GPU renders
+    assert rec["verified_against_one_gpu"] == "bit-identical"
+
+
+def test_bench_frame_split_of_three_ranks_verifies(tmp_path):
+    """The frame split (sum all-reduce, alpha back to 1) through bench.py's pipelined step loop, three rank
+    processes on this box's one GPU over gloo: the reduced image agrees with one GPU's to rounding."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--mode", "frames", "--steps", "3",
+                          "--warmup", "1", "--same-device", "--backend", "gloo", "--verify"], env=env, capture_output=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    rec = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 3
+    assert rec["verified_against_one_gpu"]["alpha_is_one"]
+    assert rec["verified_against_one_gpu"]["rmse_over_mean"] < 1e-5

@@ -601,6 +601,43 @@ def test_overlapped_calls_survive_stream_and_tracer_changes(pkg, oracle):
     t.destroy()
 
 
+def test_handles_driven_from_threads_of_their_own(pkg, oracle):
+    """A handle is single-threaded, a process need not be: four host threads, each with a tracer and a stream of
+    its own, render at the same time (one of the tracers gets the launch overlap) and every image is the oracle's."""
+    import threading
+    import torch
+    w, h, frames = 200, 120, 16
+    scene = pkg.default_scene()
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            t = make_tracer(pkg, w, h, 2 + k, 8, 0.05)
+            t.set_stream(stream.cuda_stream)
+            for f in range(frames):
+                t.render(f)
+            t.render_frames(frames, 5)
+            results[k] = (t.read_accum(), t.get_params_words(0))
+            t.destroy()
+        except BaseException as e:      # reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=100)
+    assert not errors, errors
+    assert len(results) == 4
+    for k in range(4):
+        ref = make_tracer(pkg, w, h, 2 + k, 8, 0.05)
+        want = oracle_frames(oracle, ref, scene, range(frames + 5))["accum"]
+        ref.destroy()
+        assert same(results[k][0], want)
+
+
 def test_scene_change_and_buffer_growth_behind_renders_in_flight(pkg, oracle):
     """rt_set_spheres and a growing per-frame-sum buffer wait for the handle's own kernels (an event on the
     caller's stream), not for the whole device: a scene written over the one a launch in flight still reads,

@@ -1,3 +1,8 @@
+#!/bin/bash
+# Timing rehearsals of the multi-GPU step loop on a one-GPU box: this process does rank 0's part of a job of 2, 4
+# and 8 ranks (bench.py --rehearse-world: the collective is replaced by device copies of the same size), for the
+# benchmark workload in both split modes, the 8K frame and the 4096-sphere scene; then the one-rank RCCL runs
+# and the multi-process GPU tests.  Results: gpurun_out/r2g/*.json.   Usage (GPU box): bash tools/rehearse_all.sh
 set -e
 mkdir -p gpurun_out/r2g
 p() { python -c "import json,sys; d=json.load(open('$1')); print('$2', 'ms_per_step %.3f value %.3e' % (d['ms_per_step'], d['value']))"; }

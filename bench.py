@@ -74,11 +74,13 @@ def load_hierarchy_bytes(key):
 
 def load_measured_traffic():
     """HBM bytes per trace launch of the c2 workload from the committed rocprofv3 PMC passes of this same
-    command (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE); None if not recorded.
+    command (FETCH_SIZE doubled as gfx950 requires for wide reads, plus WRITE_SIZE), with the file they were
+    read from and the other per-launch figures of those passes; (None, None, {}) if not recorded.
     Profiles of this command live in profiles/r<round><letter>/; directories with a suffix
-    (r1i_c5m ...) hold other workloads.  The most recent one wins."""
+    (r1i_c5m ...) hold other workloads.  The most recent one wins: the figure describes the kernel as it
+    was when that profile was taken, which is why its source is named in the bench line."""
     import re
-    best = None
+    best, source, derived = None, None, {}
     base = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(base)):
         path = os.path.join(base, name, "pmc_summary.json")
@@ -86,7 +88,8 @@ def load_measured_traffic():
             d = json.load(open(path)).get("_derived", {})
             if "hbm_read_bytes_per_launch" in d:
                 best = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
-    return best
+                source, derived = os.path.relpath(path, ROOT), d
+    return best, source, derived
 
 
 def host_threads():
@@ -193,6 +196,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step instead of the workload's own count")
     ap.add_argument("--mode", choices=["tiles", "frames"], default="tiles", help="how N > 1 ranks share a step")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--stripe-rows", type=int, default=0, help="rows per interleaved stripe in tiles mode (0: 4, or 16 at 8K)")
@@ -233,6 +237,8 @@ def main():
     if args.gpus != world:
         sys.exit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     wl = WORKLOADS[args.workload]
+    if args.frames > 0 and args.frames != wl["frames"]:
+        wl = dict(wl, frames=args.frames, text=wl["text"] + " [--frames %d per step]" % args.frames)
     rehearse = (args.rehearse_world, 0) if args.rehearse_world > 1 else None
     if rehearse and world != 1:
         sys.exit("--rehearse-world is for a single process")
@@ -453,10 +459,14 @@ def main():
                         "which is why the fraction is low; HBM traffic is negligible"}
         elif flops_per_sample is not None:
             achieved = flops_per_sample * launch_samples / avg_kernel_s / 1e12
+            traffic, traffic_source, pmc = load_measured_traffic() if args.workload == "c2" and not distributed else (None, None, {})
             result["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                "traffic": load_measured_traffic() if args.workload == "c2" and not distributed else None,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "lanes_per_inst": pmc.get("mean_active_lanes_per_valu_inst"),
+                "valu_insts_per_wave_sample": pmc.get("valu_insts_per_wave_sample"),
+                "simd_cycles_per_valu_inst": pmc.get("simd_cycles_per_valu_inst"),
                 "kernel_ms": avg_kernel_s * 1e3, "flops_per_sample": flops_per_sample,
                 "ceilings": {"unit": "TFLOP/s", "fma_every_slot": PEAK_FP32_VALU_TFLOPS,
                              "one_flop_per_slot": PEAK_FP32_VALU_TFLOPS / 2,
@@ -467,7 +477,9 @@ def main():
                                      "PMC figure of this kernel with the VALU saturated (profiles/r2f/pmc_summary.json)"},
                 "note": "FP32 VALU-bound kernel (no MFMA; HBM traffic is the 16 B per-frame sum per pixel per frame, "
                         "i.e. well under 100 GB/s); achieved = algorithmic FLOP per launch / HIP-event kernel time of "
-                        "rank 0's launch; traffic = bytes per launch from the committed rocprofv3 PMC passes"}
+                        "rank 0's launch; traffic, lanes_per_inst (active lanes of 64 per VALU instruction) and the two "
+                        "figures after it are per-launch means from the committed rocprofv3 PMC passes named in "
+                        "traffic_source, not from this run"}
         else:
             result["roofline"] = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                                   "frac": None, "traffic": None, "kernel_ms": avg_kernel_s * 1e3,

@@ -138,20 +138,27 @@ int rt_reset_accumulation(rt_handle h);
 /* RayTracer::render, src/rt/RayTracer.cpp:559-685: clears the accumulator iff
  * the reset flag is up or frame_index == 0 (:564), lowers the flag, then runs
  * one dispatch of the shader for frame_index (raytrace.comp.glsl:298-343) over
- * the whole image.  Asynchronous on `stream` (a hipStream_t; NULL = the
- * device's default stream), like the reference's recording into the caller's
- * command buffer.  Successive calls on one stream are ordered. */
+ * the whole image.  The GPU work is asynchronous on `stream` (a hipStream_t;
+ * NULL = the device's default stream), like the reference's recording into the
+ * caller's command buffer, and successive calls on one stream are ordered.  The
+ * call itself may block on the host for a while: with launch overlap on (the
+ * default, see rt_set_frame_overlap) it waits until the call before the previous
+ * one has been added to the accumulator, and the first overlapped call of a
+ * handle allocates its two per-frame sum images.  On a stream that is being
+ * captured into a HIP graph the call is not overlapped: everything it launches
+ * goes to `stream` and becomes part of the graph. */
 int rt_render(rt_handle h, uint32_t frame_index, void *stream);
 
 /* Consecutive single-frame calls (rt_render, or a shard call with n_frames == 1)
  * overlap on the GPU by default: the library traces call k on its own stream
- * k % 2 into a per-frame sum image (two are kept per handle, 32 bytes per pixel)
- * and adds the sums to the accumulator on the caller's stream in call order, so
+ * k % 2 into a per-frame sum image (two per handle, 32 bytes per pixel together,
+ * allocated by the first call that overlaps) and adds the sums to the accumulator
+ * on the caller's stream in call order, so
  * the end of one launch, when the GPU runs empty, is filled by the start of the
  * next.  Accumulator, output and their ordering on the caller's stream are those
  * of the plain dispatch (raytrace.comp.glsl:333-342).  enable = 0 keeps every
- * launch on the caller's stream (for callers that capture the stream into a HIP
- * graph).  The reference serialises its dispatches with a semaphore
+ * launch on the caller's stream; a call on a stream that is being captured into
+ * a HIP graph does so by itself.  The reference serialises its dispatches with a semaphore
  * (src/core/App.cpp:163-168) because each one reads the accumulator; here only
  * the short fold does.  Two consequences for the caller: an overlapped call
  * may wait on the host until the call before the previous one has been folded

@@ -152,6 +152,15 @@ hipError_t wait_for_renders(rt_tracer* h)
     if (!h->rendered || h->last_render == nullptr) {
         return hipSuccess;
     }
+    // A call that failed between its launch on one of the library's streams and the wait it queues on the
+    // caller's stream leaves a kernel that `last_render` does not cover.  The library's streams never wait
+    // on the device, so waiting for them here cannot stall.
+    for (hipStream_t side : h->pipe_stream) {
+        if (side != nullptr && hipStreamSynchronize(side) != hipSuccess) {
+            (void)hipGetLastError();
+            return hipDeviceSynchronize();
+        }
+    }
     if (hipEventSynchronize(h->last_render) == hipSuccess) {
         return hipSuccess;
     }
@@ -329,10 +338,8 @@ struct Images {
     float4* accum = nullptr;
     uint32_t* output = nullptr;
     uint32_t* rng_state = nullptr;
-    float4* pipe_partial = nullptr;
     void release()
     {
-        if (pipe_partial) { (void)hipFree(pipe_partial); pipe_partial = nullptr; }
         if (accum) { (void)hipFree(accum); accum = nullptr; }
         if (output) { (void)hipFree(output); output = nullptr; }
         if (rng_state) { (void)hipFree(rng_state); rng_state = nullptr; }
@@ -360,7 +367,6 @@ int allocate_images(rt_tracer* h, uint32_t width, uint32_t height, Images& out)
         RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.accum), pixels * sizeof(float4)));
         RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.output), pixels * sizeof(uint32_t)));
         RT_HIP_TRY(h, hipMemset(out.output, 0, pixels * sizeof(uint32_t)));
-        RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.pipe_partial), rt_tracer::kPipeSlots * pixels * sizeof(float4)));
         if (h->rng_capture) {
             RT_HIP_TRY(h, device_malloc(reinterpret_cast<void**>(&out.rng_state), pixels * sizeof(uint32_t)));
             RT_HIP_TRY(h, hipMemset(out.rng_state, 0, pixels * sizeof(uint32_t)));
@@ -662,8 +668,30 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     const uint64_t launch_rows = rows.stripe_rows != 0 ? static_cast<uint64_t>(rows.n_stripes) * rows.stripe_rows
                                                        : rows.row_end - rows.row_begin;
     const bool small_launch = launch_rows * h->width * n_frames / 512u < rt::resident_wave_slots() * 16u;
-    const bool overlap = !static_scratch && h->overlap_frames && !h->rng_capture && h->stats == nullptr &&
-                         h->pipe_partial != nullptr && (n_frames == 1 || small_launch) && claim_overlap(h);
+    // Not while the caller's stream is being captured into a HIP graph either: a launch on the library's
+    // streams would run at once instead of becoming part of the graph, and the captured stream would be
+    // told to wait for an event that is not part of the capture.  The call then stays on the caller's
+    // stream as a whole and is captured like any other work.  (A query that fails -- the legacy stream while
+    // another stream captures in global mode -- leaves the decision to the launches below, which fail the
+    // same way.)
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    bool overlap = !static_scratch && !capturing && h->overlap_frames && !h->rng_capture && h->stats == nullptr &&
+                   (n_frames == 1 || small_launch) && claim_overlap(h);
+    if (overlap && n_frames == 1 && h->pipe_partial == nullptr) {
+        // The two images single-frame launches sum into (32 bytes per pixel) are allocated when the handle
+        // overlaps for the first time: handles that never do (RNG capture, overlap switched off, the device's
+        // overlap taken by another handle) do not pay for them.  If they do not fit, the call is not overlapped.
+        if (device_malloc(reinterpret_cast<void**>(&h->pipe_partial), rt_tracer::kPipeSlots * frame_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->pipe_partial = nullptr;
+            overlap = false;
+        }
+    }
 
     // A launch of several frames keeps one float4 per (frame, pixel) in HBM and folds them into the
     // accumulator in frame order afterwards; the frames of one call are split into groups so that
@@ -950,10 +978,13 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
             RT_HIP_TRY(h, hipEventCreateWithFlags(&h->last_render, hipEventDisableTiming));
             h->overlap_frames = std::getenv("RT_NO_FRAME_OVERLAP") == nullptr;
             // the library's set-up per device: the address of the file-scope scratch array that
-            // rt_render_frames_static works in (each device holds its own copy)
+            // rt_render_frames_static works in (each device holds its own copy).  Looked up here, outside
+            // any stream capture; a failure only matters to that entry point, which looks again and reports it.
             void* scratch = nullptr;
             size_t scratch_bytes = 0;
-            RT_HIP_TRY(h, rt::static_scratch(device_id, &scratch, &scratch_bytes));
+            if (rt::static_scratch(device_id, &scratch, &scratch_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+            }
             int r = install_scene(h, std::move(scene));
             if (r != RT_OK) {
                 return r;
@@ -966,7 +997,6 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
             h->accum = images.accum;
             h->output = images.output;
             h->rng_state = images.rng_state;
-            h->pipe_partial = images.pipe_partial;
             return RT_OK;
         };
         rc = body();
@@ -1011,7 +1041,6 @@ int rt_resize(rt_handle h, uint32_t width, uint32_t height)
     h->accum = images.accum;
     h->output = images.output;
     h->rng_state = images.rng_state;
-    h->pipe_partial = images.pipe_partial;
     h->width = width;
     h->height = height;
     h->reset_accum = true; // :228
@@ -1286,6 +1315,9 @@ int rt_render_stripes(rt_handle h, uint32_t first_frame, uint32_t n_frames, uint
     if (stripe_rows == 0 || stripe_stride == 0) {
         return fail_arg(h, "stripe_rows and stripe_stride must be >= 1");
     }
+    // a stripe taller than the image is the whole image; the clamp keeps stripe_rows * width, which the
+    // kernels form in 32 bits, below width * height
+    stripe_rows = std::min(stripe_rows, h->height);
     rt::RowSet rows;
     rows.stripe_rows = stripe_rows;
     rows.stripe_first = stripe_first;

@@ -31,6 +31,28 @@ def _band_vs_oracle(pkg, oracle, t, scene, frames, bands):
     return kept
 
 
+def test_c1_720p_1spp_depth8(pkg, oracle):
+    """The configuration quoted for a CPU run of the reference shader: default scene, 1280x720, 1 spp,
+    depth 8, the application's aperture of 0.05, frame 0 -- the whole frame against the oracle: RNG words,
+    accumulator, rgba8.  Then frames 1..3 on top of it (accumulation, one call per frame as the
+    application drives it, overlapped launches) against the oracle's."""
+    scene = pkg.default_scene()
+    t = make_tracer(pkg, 1280, 720, 1, 8, 0.05)
+    t.enable_rng_capture(True)
+    t.render(0)
+    ref = oracle_frames(oracle, t, scene, [0], want_rng=True)
+    assert same(t.read_rng_state(), ref["rng"])
+    assert same(t.read_accum(), ref["accum"])
+    assert same(t.read_output(), ref["output"])
+    t.enable_rng_capture(False)     # consecutive single-frame calls then overlap on the library's streams
+    for f in (1, 2, 3):
+        t.render(f)
+    ref = oracle_frames(oracle, t, scene, [1, 2, 3], accum=ref["accum"])
+    assert same(t.read_accum(), ref["accum"])
+    assert same(t.read_output(), ref["output"])
+    t.destroy()
+
+
 def test_c3_4k_64spp_depth16_dof(pkg, oracle):
     """3840x2160, 64 spp per frame, depth 16, thin-lens depth of field on, accumulation to 4096 spp."""
     w, h = 3840, 2160

@@ -102,3 +102,44 @@ def test_static_scratch_entry_point_inside_a_stream_capture(pkg, scene_size):
     del graph
     t.destroy()
     ref.destroy()
+
+
+@pytest.mark.parametrize("scene_size", [5, 200])
+def test_plain_render_inside_a_stream_capture(pkg, scene_size):
+    """rt_render with the library's defaults (launch overlap on) on a stream that is being captured: the
+    library sees the capture and keeps the whole call on the caller's stream, so it becomes part of the
+    graph instead of running at once on the library's own streams.  One frame needs no per-frame sums, so
+    nothing is allocated either.  Replays leave the image of an ordinary call."""
+    import torch
+    w, h = 320, 200
+    scene = pkg.default_scene() if scene_size == 5 else pkg.synthetic_scene(scene_size)
+    ref = make_tracer(pkg, w, h, 2, 6, 0.05, scene=scene)
+    ref.render(0)
+    want_accum, want_output = ref.read_accum(), ref.read_output()
+    ref.render(1)
+    want_accum2, want_output2 = ref.read_accum(), ref.read_output()
+    stream = torch.cuda.Stream()
+    t = make_tracer(pkg, w, h, 2, 6, 0.05, scene=scene)
+    t.set_stream(stream.cuda_stream)
+    t.render(0)                      # an ordinary, overlapped call first: the handle owns the device's overlap
+    t.synchronize()
+    assert same(t.read_accum(), want_accum)
+    marker = np.full((h, w, 4), 7.0, dtype=np.float32)
+    t.write_accum(marker)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        t.render(0)                  # frame 0 clears, then traces: both captured
+    assert same(t.read_accum(), marker)             # captured, not run
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert same(t.read_accum(), want_accum)
+        assert same(t.read_output(), want_output)
+    # and the handle goes on outside the graph, overlapped again
+    t.render(1)
+    t.synchronize()
+    assert same(t.read_accum(), want_accum2)
+    assert same(t.read_output(), want_output2)
+    del graph
+    t.destroy()
+    ref.destroy()

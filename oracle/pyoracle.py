@@ -55,6 +55,34 @@ def build(force=False):
 
 
 _lib = None
+_variant = None
+_VARIANT_PATH = os.path.join(_HERE, "librt_oracle_variant.so")
+
+
+def cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+def variant_lib():
+    """The same restatement built as another conforming GLSL implementation would evaluate it (contracted
+    multiply-adds, the C library's pow): oracle/Makefile, target `variant`.  Only for measuring how far such an
+    implementation lands from the strict oracle; never a reference for anything.  None on a CPU without FMA."""
+    global _variant
+    if _variant is None:
+        if not cpu_has_fma():
+            return None
+        src = os.path.join(_HERE, "rt_oracle.c")
+        if not os.path.exists(_VARIANT_PATH) or os.path.getmtime(_VARIANT_PATH) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "variant"], stdout=subprocess.DEVNULL)
+        _variant = _declare(ctypes.CDLL(_VARIANT_PATH))
+    return _variant
 
 
 def lib():
@@ -62,40 +90,43 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = ctypes.CDLL(_LIB_PATH)
-        u32p = ctypes.POINTER(ctypes.c_uint32)
-        f32p = ctypes.POINTER(ctypes.c_float)
-        L.rto_hash3.restype = ctypes.c_uint32
-        L.rto_hash3.argtypes = [ctypes.c_uint32] * 3
-        L.rto_lcg.restype = ctypes.c_uint32
-        L.rto_lcg.argtypes = [u32p]
-        L.rto_rand.restype = ctypes.c_float
-        L.rto_rand.argtypes = [u32p]
-        for fn in (L.rto_log2f, L.rto_exp2f):
-            fn.restype = ctypes.c_float
-            fn.argtypes = [ctypes.c_float]
-        L.rto_powf.restype = ctypes.c_float
-        L.rto_powf.argtypes = [ctypes.c_float, ctypes.c_float]
-        L.rto_default_scene.argtypes = [ctypes.POINTER(Sphere)]
-        L.rto_normalize3.argtypes = [f32p, f32p]
-        L.rto_builtin.restype = ctypes.c_int
-        L.rto_builtin.argtypes = [ctypes.c_char_p, f32p, f32p]
-        L.rto_make_camera_params.argtypes = [f32p, f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                             ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Params)]
-        L.rto_default_aim.argtypes = [f32p, f32p, f32p]
-        L.rto_render.restype = ctypes.c_int
-        L.rto_render.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Sphere), ctypes.c_void_p, ctypes.c_void_p,
-                                 ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
-                                 ctypes.POINTER(Counters)]
-        L.rto_resolve.restype = None
-        L.rto_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
-        L.rto_hit_sphere.restype = ctypes.c_int
-        L.rto_hit_sphere.argtypes = [ctypes.POINTER(Sphere), f32p, f32p, ctypes.c_float, ctypes.c_float,
-                                     f32p, f32p, f32p, ctypes.POINTER(ctypes.c_int)]
-        L.rto_sample.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Sphere), ctypes.c_uint32, ctypes.c_uint32,
-                                 u32p, f32p]
-        _lib = L
+        _lib = _declare(ctypes.CDLL(_LIB_PATH))
     return _lib
+
+
+def _declare(L):
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    L.rto_hash3.restype = ctypes.c_uint32
+    L.rto_hash3.argtypes = [ctypes.c_uint32] * 3
+    L.rto_lcg.restype = ctypes.c_uint32
+    L.rto_lcg.argtypes = [u32p]
+    L.rto_rand.restype = ctypes.c_float
+    L.rto_rand.argtypes = [u32p]
+    for fn in (L.rto_log2f, L.rto_exp2f):
+        fn.restype = ctypes.c_float
+        fn.argtypes = [ctypes.c_float]
+    L.rto_powf.restype = ctypes.c_float
+    L.rto_powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    L.rto_default_scene.argtypes = [ctypes.POINTER(Sphere)]
+    L.rto_normalize3.argtypes = [f32p, f32p]
+    L.rto_builtin.restype = ctypes.c_int
+    L.rto_builtin.argtypes = [ctypes.c_char_p, f32p, f32p]
+    L.rto_make_camera_params.argtypes = [f32p, f32p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(Params)]
+    L.rto_default_aim.argtypes = [f32p, f32p, f32p]
+    L.rto_render.restype = ctypes.c_int
+    L.rto_render.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Sphere), ctypes.c_void_p, ctypes.c_void_p,
+                             ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
+                             ctypes.POINTER(Counters)]
+    L.rto_resolve.restype = None
+    L.rto_resolve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+    L.rto_hit_sphere.restype = ctypes.c_int
+    L.rto_hit_sphere.argtypes = [ctypes.POINTER(Sphere), f32p, f32p, ctypes.c_float, ctypes.c_float,
+                                 f32p, f32p, f32p, ctypes.POINTER(ctypes.c_int)]
+    L.rto_sample.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Sphere), ctypes.c_uint32, ctypes.c_uint32,
+                             u32p, f32p]
+    return L
 
 
 def _f3(v):
@@ -172,8 +203,9 @@ def params_from_words(words):
 
 
 def render(params, spheres, accum=None, want_output=True, want_rng=False, y0=0, y1=None, nthreads=None,
-           want_counters=False):
-    """One dispatch of the shader over rows [y0, y1).  spheres: (N, 12) float32.
+           want_counters=False, library=None):
+    """One dispatch of the shader over rows [y0, y1).  spheres: (N, 12) float32.  library: the build to run
+    (default: the strict oracle; variant_lib() for the conforming-variant build).
 
     Returns dict(accum=(H,W,4) float32, output=(H,W,4) uint8 or None, rng=(H,W) uint32 or None,
     counters=dict or None).  accum is updated in place when given.
@@ -194,7 +226,7 @@ def render(params, spheres, accum=None, want_output=True, want_rng=False, y0=0, 
     out = np.zeros((H, W, 4), dtype=np.uint8) if want_output else None
     rng = np.zeros((H, W), dtype=np.uint32) if want_rng else None
     cnt = Counters() if want_counters else None
-    rc = lib().rto_render(ctypes.byref(params), sph.ctypes.data_as(ctypes.POINTER(Sphere)),
+    rc = (library or lib()).rto_render(ctypes.byref(params), sph.ctypes.data_as(ctypes.POINTER(Sphere)),
                           accum.ctypes.data, out.ctypes.data if out is not None else None,
                           rng.ctypes.data if rng is not None else None, y0, y1, nthreads,
                           ctypes.byref(cnt) if cnt is not None else None)

@@ -146,6 +146,11 @@ float rto_exp2f(float p)
 
 float rto_powf(float x, float y)
 {
+#ifdef RTO_LIBM_POW
+    /* the conforming-variant build (oracle/Makefile, target `variant`): pow as the C library rounds it, one
+     * of the many precisions GLSL allows an implementation */
+    return powf(x, y);
+#endif
     if (x == 0.0f) {
         return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : u2f(0x7f800000u));
     }

@@ -1243,15 +1243,18 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     args.frames_per_unit = std::min(std::min(args.frames_per_unit, 64u), args.n_frames);
     if (args.tile_w_log2 > 4u || args.tile_h_log2 > 4u) {
         // Not chosen by the caller: a unit pools about 512 items, from as many frames and as few
-        // pixels as the launch allows (between 2 x 4 and 8 x 8 pixels).  Measured on the benchmark
+        // pixels as the launch allows (between 2 x 4 and 8 x 8 pixels; 8 x 16 where the host asks for it).  Measured on the benchmark
         // (64 frames): 8 x 8 pixels x 16 frames 55.0 Gsamples/s, 8 x 8 x 8 56.6, 4 x 4 x 16 57.2,
         // 2 x 4 x 32 57.8, 2 x 4 x 64 58.2; the number of VALU instructions is the same in all of
         // them, the shorter and more numerous units keep more waves resident.
         // With the hierarchy units are handed out by a counter, so they can be much smaller: about 32
         // items.  Rays of neighbouring pixels, and of one pixel in several frames, walk the same nodes
         // (4096 spheres, 960 x 540, 4 frames: 8 x 8 pixels 31.3 ms, 4 x 8 22.5, 4 x 4 19.9, 2 x 4 19.4,
-        // 2 x 2 20.2, 1 x 1 20.5).
-        uint32_t target_items = args.tree_nodes != 0 ? 32u : 512u;
+        // 2 x 2 20.2, 1 x 1 20.5).  Launches of many frames do better with more frames of the same few pixels
+        // in a unit (8 pixels x 8 or 16 frames): 4096 spheres, 1920 x 1080, depth 50, units of 32 / 64 / 128 / 256
+        // items: 8 frames 97.8 / 95.2 / 96.3 / 101.7 ms, 16 frames 191.1 / 184.5 / 183.8 / 187.5 ms, 32 frames
+        // 378.0 / 363.8 / 359.9 / 361.3 ms.
+        uint32_t target_items = args.tree_nodes != 0 ? (args.n_frames >= 16u ? 128u : (args.n_frames >= 8u ? 64u : 32u)) : 512u;
         if (args.tree_nodes == 0) {
             // A launch ends with a drain phase about as long as one unit (1 to 2 ms for 512 items of the
             // benchmark), which a launch of 30 rounds of units does not notice and a launch of 4 rounds

@@ -152,8 +152,9 @@ def spheres_to_ctypes(spheres):
 class RayTracer:
     """Python mirror of class RayTracer (src/rt/RayTracer.h:34-94) over the C ABI."""
 
-    def __init__(self):
-        self._lib = load_library()
+    def __init__(self, lib=None):
+        """lib: another build of the library from load_library(path) (A/B comparisons); default: the shipped one."""
+        self._lib = lib if lib is not None else load_library()
         self._h = _H()
         self._stream = None
 

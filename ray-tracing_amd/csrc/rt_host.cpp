@@ -52,7 +52,13 @@ struct rt_tracer {
     size_t partial2_bytes = 0;
     uint32_t* stats = nullptr;        // diagnostic builds only
     rt::SphereTree tree;              // hierarchy over `spheres` (empty for small or out-of-range scenes)
+    rt::QuadTree quad;                // the same as a complete four-way tree, when that fits LDS (else empty)
     bool use_tree = true;
+    bool use_quad = true;             // walk the four-way tree where there is one
+    float4* d_quad_geom = nullptr;    // four float4 per group
+    rt_gpu_sphere* d_slot_spheres = nullptr; // the sphere list in slot order of the four-way tree
+    uint32_t d_quad_capacity = 0;     // groups
+    uint32_t d_slot_capacity = 0;     // slots
     bool scene_bounded = false;       // every sphere finite, |centre| and |radius| at most 2^20
     float4* d_tree_geom = nullptr;
     uint32_t* d_tree_word = nullptr;
@@ -384,6 +390,7 @@ int allocate_images(rt_tracer* h, uint32_t width, uint32_t height, Images& out)
 struct SceneIndex {
     bool bounded = true;
     rt::SphereTree tree;
+    rt::QuadTree quad;
 };
 
 void index_scene(const std::vector<rt_gpu_sphere>& spheres, SceneIndex& out)
@@ -397,6 +404,7 @@ void index_scene(const std::vector<rt_gpu_sphere>& spheres, SceneIndex& out)
         }
     }
     (void)rt::build_sphere_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.tree); // empty when the scene does not qualify
+    (void)rt::build_quad_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.quad);   // empty as well when it would not fit LDS
 }
 
 // A device buffer that is either the handle's current one (large enough) or a fresh allocation
@@ -426,6 +434,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
     if (h->device < 0) {
         h->spheres = std::move(spheres);
         h->tree = std::move(index.tree);
+        h->quad = std::move(index.quad);
         h->scene_bounded = index.bounded;
         return RT_OK;
     }
@@ -459,6 +468,21 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
             }
         }
     }
+    // the four-way tree: its groups, and the sphere records in slot order with the sphere's index in the unused
+    // fourth albedo component (all ones for an unused slot)
+    const uint32_t quad_groups = index.quad.group_count();
+    const uint32_t quad_slots = index.quad.slot_count();
+    std::vector<rt_gpu_sphere> slot_spheres;
+    if (quad_groups != 0) {
+        slot_spheres.assign(quad_slots, rt_gpu_sphere{});
+        for (uint32_t slot = 0; slot < quad_slots; ++slot) {
+            const uint32_t sphere = index.quad.slot_sphere[slot];
+            if (sphere != rt::kTreeNoSphere) {
+                slot_spheres[slot] = spheres[sphere];
+            }
+            std::memcpy(&slot_spheres[slot].albedo[3], &sphere, sizeof sphere);
+        }
+    }
     std::vector<float> loop_geom;
     if (n > rt::kMaxSpheresGeomLds) {
         // (centre, radius^2) records for the loop over all spheres in global memory
@@ -474,7 +498,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
 
     // the previous scene may still be read by one of the handle's kernels in flight
     RT_HIP_TRY(h, wait_for_renders(h));
-    Staged d_spheres, d_tree_geom, d_tree_word, d_loop_geom, d_counter;
+    Staged d_spheres, d_tree_geom, d_tree_word, d_loop_geom, d_counter, d_quad_geom, d_slot_spheres;
     auto body = [&]() -> int {
         RT_HIP_TRY(h, d_spheres.take(h->d_spheres, h->d_sphere_capacity, n, n * sizeof(rt_gpu_sphere)));
         if (nodes != 0) {
@@ -484,6 +508,10 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
         }
         if (!loop_geom.empty()) {
             RT_HIP_TRY(h, d_loop_geom.take(h->d_loop_geom, h->d_loop_geom_capacity, n, static_cast<size_t>(n) * sizeof(float4)));
+        }
+        if (quad_groups != 0) {
+            RT_HIP_TRY(h, d_quad_geom.take(h->d_quad_geom, h->d_quad_capacity, quad_groups, static_cast<size_t>(quad_groups) * 4u * sizeof(float4)));
+            RT_HIP_TRY(h, d_slot_spheres.take(h->d_slot_spheres, h->d_slot_capacity, quad_slots, static_cast<size_t>(quad_slots) * sizeof(rt_gpu_sphere)));
         }
         return RT_OK;
     };
@@ -499,6 +527,10 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
             }
             if (!loop_geom.empty()) {
                 RT_HIP_TRY(h, hipMemcpy(d_loop_geom.ptr, loop_geom.data(), loop_geom.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            if (quad_groups != 0) {
+                RT_HIP_TRY(h, hipMemcpy(d_quad_geom.ptr, index.quad.geom.data(), index.quad.geom.size() * sizeof(float), hipMemcpyHostToDevice));
+                RT_HIP_TRY(h, hipMemcpy(d_slot_spheres.ptr, slot_spheres.data(), slot_spheres.size() * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice));
             }
             return RT_OK;
         };
@@ -516,6 +548,8 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
         d_tree_word.drop();
         d_loop_geom.drop();
         d_counter.drop();
+        d_quad_geom.drop();
+        d_slot_spheres.drop();
         return rc;
     }
     // commit
@@ -540,8 +574,19 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
         h->d_loop_geom = static_cast<float4*>(d_loop_geom.ptr);
         h->d_loop_geom_capacity = n;
     }
+    if (d_quad_geom.fresh) {
+        if (h->d_quad_geom) { (void)hipFree(h->d_quad_geom); }
+        h->d_quad_geom = static_cast<float4*>(d_quad_geom.ptr);
+        h->d_quad_capacity = quad_groups;
+    }
+    if (d_slot_spheres.fresh) {
+        if (h->d_slot_spheres) { (void)hipFree(h->d_slot_spheres); }
+        h->d_slot_spheres = static_cast<rt_gpu_sphere*>(d_slot_spheres.ptr);
+        h->d_slot_capacity = quad_slots;
+    }
     h->spheres = std::move(spheres);
     h->tree = std::move(index.tree);
+    h->quad = std::move(index.quad);
     h->scene_bounded = index.bounded;
     return RT_OK;
 }
@@ -636,6 +681,7 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
     const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
     const size_t frame_bytes = image_pixels * sizeof(float4);
     const bool tree = h->use_tree && !h->tree.empty();
+    const bool quad = tree && h->use_quad && !h->quad.empty() && h->d_quad_geom != nullptr && h->d_slot_spheres != nullptr;
 
     // Workspace of this call: per-frame sums (launches of several frames) and the unit counter (hierarchy).
     float4* partial = h->partial;
@@ -794,7 +840,18 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.tree_word = tree ? h->d_tree_word : nullptr;
         args.unit_counter = tree ? unit_counter : nullptr;
         args.tree_nodes = tree ? h->tree.node_count() : 0u;
-        args.tree_packed = tree && h->tree.packed() ? 1u : 0u;
+        args.tree_packed = tree && h->tree.packed() ? rt::kTreeFormatPacked : rt::kTreeFormatGlobal;
+        args.quad_roots = args.quad_first_leaf = args.quad_prologue = 0u;
+        if (quad) {
+            args.tree_geom = h->d_quad_geom;
+            args.tree_word = nullptr;
+            args.tree_nodes = h->quad.group_count();
+            args.tree_packed = rt::kTreeFormatQuad;
+            args.quad_roots = h->quad.roots;
+            args.quad_first_leaf = h->quad.first_leaf;
+            args.quad_prologue = h->quad.has_prologue ? 1u : 0u;
+            args.spheres = h->d_slot_spheres; // `best` of that walk is a slot
+        }
         args.loop_geom = h->d_loop_geom;
         args.scene_bounded = h->scene_bounded ? 1u : 0u;
         args.width = h->width;
@@ -938,6 +995,7 @@ int rt_create(int device_id, uint32_t width, uint32_t height, rt_handle* out)
     h->width = width;
     h->height = height;
     h->reset_accum = true;
+    h->use_quad = std::getenv("RT_TREE_DEPTH_FIRST") == nullptr; // experiments: the one-node-per-step walk everywhere
     init_default_state(h);
     std::vector<rt_gpu_sphere> scene;
     build_default_scene(scene);
@@ -1062,6 +1120,8 @@ int rt_destroy(rt_handle h)
         if (h->d_tree_word) { (void)hipFree(h->d_tree_word); }
         if (h->d_unit_counter) { (void)hipFree(h->d_unit_counter); }
         if (h->d_loop_geom) { (void)hipFree(h->d_loop_geom); }
+        if (h->d_quad_geom) { (void)hipFree(h->d_quad_geom); }
+        if (h->d_slot_spheres) { (void)hipFree(h->d_slot_spheres); }
         for (uint32_t i = 0; i < rt_tracer::kTimedLaunches; ++i) {
             if (h->ev_start[i]) { (void)hipEventDestroy(h->ev_start[i]); }
             if (h->ev_stop[i]) { (void)hipEventDestroy(h->ev_stop[i]); }
@@ -1192,6 +1252,7 @@ int rt_set_scene_hierarchy(rt_handle h, int enable)
         return RT_ERR_BAD_ARGUMENT;
     }
     h->use_tree = enable != 0;
+    h->use_quad = enable != 2;
     return RT_OK;
 }
 
@@ -1258,6 +1319,31 @@ int rt_get_scene_hierarchy_links(rt_handle h, float* geom, uint32_t* link, uint3
     }
     if (sphere != nullptr && take != 0) {
         std::memcpy(sphere, h->tree.sphere.data(), sizeof(uint32_t) * take);
+    }
+    return RT_OK;
+}
+
+int rt_get_scene_quadtree(rt_handle h, float* geom, uint32_t* slot_sphere, uint32_t group_cap, uint32_t slot_cap,
+                          uint32_t* n_groups, uint32_t* n_slots, uint32_t* levels, uint32_t* roots, uint32_t* first_leaf,
+                          int* has_prologue)
+{
+    if (h == nullptr) {
+        return RT_ERR_BAD_ARGUMENT;
+    }
+    const rt::QuadTree& q = h->quad;
+    if (n_groups) { *n_groups = q.group_count(); }
+    if (n_slots) { *n_slots = q.slot_count(); }
+    if (levels) { *levels = q.levels; }
+    if (roots) { *roots = q.roots; }
+    if (first_leaf) { *first_leaf = q.first_leaf; }
+    if (has_prologue) { *has_prologue = q.has_prologue ? 1 : 0; }
+    const uint32_t groups = std::min(group_cap, q.group_count());
+    if (geom != nullptr && groups != 0) {
+        std::memcpy(geom, q.geom.data(), sizeof(float) * 16u * groups);
+    }
+    const uint32_t slots = std::min(slot_cap, q.slot_count());
+    if (slot_sphere != nullptr && slots != 0) {
+        std::memcpy(slot_sphere, q.slot_sphere.data(), sizeof(uint32_t) * slots);
     }
     return RT_OK;
 }

@@ -160,6 +160,7 @@ enum SceneMode {
     kTree = 2,    // hierarchy nodes in LDS, sphere records read from memory for the winner
     kTreeGlobal = 3, // hierarchy too large for LDS (or for the packed node word): walked in global memory
     kGeomGlobal = 4, // no hierarchy and too many spheres for LDS: geometry records read from global memory
+    kTreeQuad = 6,   // the complete four-way tree (rt_tree.hpp: QuadTree) in LDS, four balls per trip of the walk
     kFullLds5 = 5    // kFullLds for exactly five spheres (the reference's own scene, src/rt/RayTracer.cpp:105-138):
                      // the sphere loop is unrolled and every LDS offset is a constant
 };
@@ -196,6 +197,15 @@ __device__ __forceinline__ void stage_tree(const float4* __restrict__ node_geom,
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
         geom[i] = node_geom[i];
         word[i] = node_word[i];
+    }
+    __syncthreads();
+}
+
+// Copies the groups of the four-way tree into LDS (four float4 per group).
+__device__ __forceinline__ void stage_quad_tree(const float4* __restrict__ group_geom, uint32_t groups, float4* geom)
+{
+    for (uint32_t i = threadIdx.x; i < 4u * groups; i += blockDim.x) {
+        geom[i] = group_geom[i];
     }
     __syncthreads();
 }
@@ -297,7 +307,13 @@ struct TreeWalk {
     float4 g;            // the node at `at`, fetched ahead
     uint32_t w;
     uint32_t link;       // byte offset of the node to continue at when this node's test fails
+    // the four-way tree instead of `at`, `g`, `w`, `link`:
+    uint32_t grp;        // this lane's group; kQuadIdle: no walk in progress
+    uint32_t stack;      // four bits per level above `grp`: the siblings on that level that passed their parent's
+                         // test and have not been visited yet (lowest four bits: the siblings of `grp` itself)
+    uint32_t root;       // the level-0 group the walk is below (0xFFFFFFFF while it is in the prologue)
 };
+constexpr uint32_t kQuadIdle = 0xFFFFFFFFu;
 
 // One node's words: packed (one word, rt_tree.hpp) or wide (continuation offset, then leaf flag | sphere index).
 template <bool WIDE>
@@ -404,6 +420,138 @@ __device__ __forceinline__ void tree_walk(const TraceArgs& A, const float4* geom
     } while ((uint32_t)__popcll(wave_ballot(t.at < end)) > few);
 }
 
+// The sphere index kept with slot `slot` of the sphere list in slot order (TraceArgs::spheres of the four-way tree).
+__device__ __forceinline__ uint32_t slot_sphere_index(const rt_gpu_sphere* slot_spheres, int slot)
+{
+    return __float_as_uint(slot_spheres[slot].albedo[3]);
+}
+
+// sphere_closest_any_order for the four-way tree, where a sphere is known by its slot: the smaller root wins, and
+// of exactly equal roots the higher SPHERE index (:125 does not reject root == closest, and the shader's loop runs in
+// index order), which is looked up only when such a tie occurs.
+template <class Stats>
+__device__ __forceinline__ void sphere_closest_slot(const SphereQuadratic& q, const RayDenominator& rden, float tmin, int slot,
+                                                    const rt_gpu_sphere* slot_spheres, float& closest, int& best, Stats& st)
+{
+    st.section(ST_ROOT);
+    const float sqrt_disc = sqrt_exact(q.discriminant);
+    float root = root_div(-q.half_b - sqrt_disc, rden);
+    if (root < tmin || root > closest) {
+        st.section(ST_FAR_ROOT);
+        root = root_div(-q.half_b + sqrt_disc, rden);
+        if (root < tmin || root > closest) {
+            return;
+        }
+    }
+    bool take = root < closest;
+    if (!take) {
+        RT_COLD_PATH();
+        take = best < 0 || slot_sphere_index(slot_spheres, slot) > slot_sphere_index(slot_spheres, best);
+    }
+    if (take) {
+        RT_KEEP_BRANCH();
+        closest = root;
+        best = slot;
+    }
+}
+
+// Walk of the complete four-way tree (rt_tree.hpp: QuadTree), resumable like tree_walk.  One trip = one group:
+// its four balls are fetched together and tested independently.  In a group of the last level (and in the
+// prologue) they are spheres, and those that pass go through the root arithmetic one after the other; in a group
+// above, the children whose ball passes are visited one after the other, the not yet visited ones waiting as four
+// bits of `stack`.  The tree is implicit (child k of group g is 4 g + roots + k), so going down, across and up
+// is arithmetic on the group index and needs no memory access.  `best` is a slot of the sphere list in slot order.
+template <class Stats>
+__device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* groups, bool live, f3 ro, f3 rd, TreeWalk& t, Stats& st)
+{
+    const uint32_t roots = A.quad_roots, first_leaf = A.quad_first_leaf;
+    if (live && t.grp == kQuadIdle) {
+        // a new segment
+        t.closest = 1e20f;
+        t.best = -1;
+        t.beyond_limit = __builtin_inff();
+        t.rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
+        // the skip tests of the hierarchy are proven for rays in the bounded range only
+        if (t.rden.bounded) {
+            t.stack = 0u;
+            t.root = A.quad_prologue != 0u ? 0xFFFFFFFFu : 0u;
+            t.grp = A.quad_prologue != 0u ? A.tree_nodes - 1u : 0u;
+        } else {
+            RT_COLD_PATH();
+            const uint32_t slots = 4u * (A.tree_nodes - first_leaf);
+            for (uint32_t s = 0; s < slots; ++s) {
+                const float4* rec = reinterpret_cast<const float4*>(A.spheres + s);
+                if (__float_as_uint(rec[1].w) == 0xFFFFFFFFu) {
+                    continue; // an unused slot
+                }
+                const float4 cr = rec[0];
+                const SphereQuadratic q = sphere_quadratic(make_float4(cr.x, cr.y, cr.z, cr.w * cr.w), ro, rd, t.rden.a);
+                if (!(q.discriminant < 0.0f)) {
+                    sphere_closest_slot(q, t.rden, kTMin, (int)s, A.spheres, t.closest, t.best, st);
+                }
+            }
+        }
+    }
+    // the round ends when fewer than this many lanes are still walking
+    const uint32_t in_loop = (uint32_t)__popcll(wave_ballot(true));
+    const uint32_t few = __builtin_amdgcn_readfirstlane(kWalkQuorum != 0u && in_loop > kWalkQuorum ? in_loop - kWalkQuorum : 0u);
+    if ((uint32_t)__popcll(wave_ballot(t.grp != kQuadIdle)) <= few) {
+        return;
+    }
+    do {
+        if (t.grp != kQuadIdle) {
+            st.section(ST_NODE);
+            const float4* g = groups + 4u * t.grp;
+            const float4 b0 = g[0], b1 = g[1], b2 = g[2], b3 = g[3];
+            const bool leaf = t.grp >= first_leaf;
+            // dot(oc,oc) is scaled by 1 - 2^-13 for a bounding ball and by exactly 1 for a sphere
+            const float k = leaf ? 1.0f : __uint_as_float(0x3F7FF800u);
+            const SphereQuadratic q0 = sphere_quadratic_scaled(b0, ro, rd, t.rden.a, k);
+            const SphereQuadratic q1 = sphere_quadratic_scaled(b1, ro, rd, t.rden.a, k);
+            const SphereQuadratic q2 = sphere_quadratic_scaled(b2, ro, rd, t.rden.a, k);
+            const SphereQuadratic q3 = sphere_quadratic_scaled(b3, ro, rd, t.rden.a, k);
+            // the three reasons to leave a ball out, as in tree_walk
+            const bool s0 = q0.discriminant < 0.0f || behind_origin(q0.half_b, q0.c) || q0.c - b0.w > t.beyond_limit;
+            const bool s1 = q1.discriminant < 0.0f || behind_origin(q1.half_b, q1.c) || q1.c - b1.w > t.beyond_limit;
+            const bool s2 = q2.discriminant < 0.0f || behind_origin(q2.half_b, q2.c) || q2.c - b2.w > t.beyond_limit;
+            const bool s3 = q3.discriminant < 0.0f || behind_origin(q3.half_b, q3.c) || q3.c - b3.w > t.beyond_limit;
+            const uint32_t pass = (s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u);
+            if (leaf) {
+                const int slot0 = (int)(4u * (t.grp - first_leaf));
+                for (uint32_t m = pass; m != 0u; m &= m - 1u) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(m);
+                    SphereQuadratic q = q0;
+                    if (i == 1u) { q = q1; }
+                    if (i == 2u) { q = q2; }
+                    if (i == 3u) { q = q3; }
+                    sphere_closest_slot(q, t.rden, kTMin, slot0 + (int)i, A.spheres, t.closest, t.best, st);
+                    t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
+                }
+            }
+            if (!leaf && pass != 0u) {
+                // down to the first child that passed; the others wait
+                t.stack = (t.stack << 4) | (pass & (pass - 1u));
+                t.grp = 4u * t.grp + roots + (uint32_t)__builtin_ctz(pass);
+            } else if (t.stack == 0u) {
+                // nothing waits below this root: on to the next one
+                t.root += 1u;
+                t.grp = t.root < roots ? t.root : kQuadIdle;
+            } else {
+                // up to the nearest level where a sibling waits, and across to it
+                uint32_t up = (uint32_t)__builtin_ctz(t.stack) >> 2;
+                t.stack >>= 4u * up;
+                uint32_t at = t.grp;
+                for (; up != 0u; --up) {
+                    at = (at - roots) >> 2;
+                }
+                const uint32_t i = (uint32_t)__builtin_ctz(t.stack);
+                t.stack &= t.stack - 1u;
+                t.grp = ((at - roots) & ~3u) + roots + i;
+            }
+        }
+    } while ((uint32_t)__popcll(wave_ballot(t.grp != kQuadIdle)) > few);
+}
+
 // A unit of work: a pixel tile x a chunk of frames, pooled by one wave.  Its description lives in
 // LDS behind the wave's hash tables (it is only needed when a lane decodes a new item, and scalar
 // registers are scarce in the trace loop); only the item count stays in a register.
@@ -507,9 +655,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t sphere_count = MODE == kFullLds5 ? 5u : A.params.frame_sample_depth_count[3];
     // records ahead of the hash tables: the scene (1 or 4 float4 per sphere) or the hierarchy
     // (a float4 and a word per node)
-    constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal;
+    constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal || MODE == kTreeQuad;
     constexpr bool IN_GLOBAL = MODE == kTreeGlobal || MODE == kGeomGlobal; // nothing but the hash tables in LDS
-    const uint32_t lds_records = IN_GLOBAL ? 0u : (MODE == kTree ? A.tree_nodes : sphere_count);
+    const uint32_t lds_records = IN_GLOBAL ? 0u : (MODE == kTree ? A.tree_nodes : (MODE == kTreeQuad ? 4u * A.tree_nodes : sphere_count));
     float4* lds_geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
@@ -520,6 +668,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     // per-wave tables of the three hash terms of :37-44 for this unit's columns, rows and frames
     // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
     uint32_t* hash_tab = (MODE == kTree ? lds_word + lds_records
+                          : MODE == kTreeQuad ? lds_word
                                         : reinterpret_cast<uint32_t*>(lds + (IN_GLOBAL ? 0u : (MAT_IN_LDS ? 4u : 1u)) * sphere_count)) +
                          (threadIdx.x >> 6) * kWaveTableWords;
 
@@ -544,6 +693,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     // both end with the workgroup barrier
     if (MODE == kTree) {
         stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, lds_geom, lds_word);
+    } else if (MODE == kTreeQuad) {
+        stage_quad_tree(A.tree_geom, A.tree_nodes, lds_geom);
     } else if (!IN_GLOBAL) {
         stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, lds_geom, mat0, mat1, hit_rec);
     }
@@ -640,6 +791,9 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     walk.rden.rcp_a = 1.0f;
     walk.rden.a_ok = true;
     walk.rden.bounded = false;
+    walk.grp = kQuadIdle;
+    walk.stack = 0u;
+    walk.root = 0u;
 
     for (;;) {
         st.section(ST_ITER);
@@ -664,7 +818,13 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         if (Stats::kEnabled && live && wave_ballot(live && depth != 0u) == 0ull) {
             st.section(ST_ALL_PRIMARY); // every ray of the wave in this iteration is a camera ray
         }
-        if (TREE) {
+        if (MODE == kTreeQuad) {
+            quad_walk(A, geom, live, ro, rd, walk, st);
+            traced = live && walk.grp == kQuadIdle;
+            closest = walk.closest;
+            best = traced ? walk.best : -1;
+            rden = walk.rden;
+        } else if (TREE) {
             tree_walk<MODE == kTreeGlobal>(A, geom, node_word, sphere_count, live, ro, rd, walk, st);
             traced = live && walk.at >= A.tree_nodes * 16u;
             closest = walk.closest;
@@ -1313,6 +1473,22 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         }
     }
     if (args.tree_nodes != 0) {
+        if (args.tree_packed == kTreeFormatQuad) {
+            if (args.tree_geom == nullptr || args.tree_nodes > kQuadMaxGroups || args.quad_roots == 0u || args.quad_roots > kQuadMaxRoots ||
+                args.quad_first_leaf >= args.tree_nodes) {
+                return hipErrorInvalidValue;
+            }
+            // 64 bytes per group; the block size follows the footprint as below
+            const size_t groups_bytes = (size_t)args.tree_nodes * 64u;
+            if (groups_bytes <= 30u * 1024u) {
+                launch_trace_as<kTreeQuad, 256, kByCounter>(args, units, groups_bytes + 4u * kWaveTableWords * 4u, stream);
+            } else if (groups_bytes <= 72u * 1024u) {
+                launch_trace_as<kTreeQuad, 512, kByCounter>(args, units, groups_bytes + 8u * kWaveTableWords * 4u, stream);
+            } else {
+                launch_trace_as<kTreeQuad, 1024, kByCounter>(args, units, groups_bytes + 16u * kWaveTableWords * 4u, stream);
+            }
+            return hipGetLastError();
+        }
         if (args.tree_geom == nullptr || args.tree_word == nullptr || (args.tree_packed != 0 && args.tree_nodes > kTreeMaxNodes)) {
             return hipErrorInvalidValue;
         }

@@ -18,6 +18,8 @@ constexpr uint32_t kMaxSpheresGeomLds = 4096;
 // Largest sphere count the tracer accepts.
 constexpr uint32_t kMaxSpheres = 1u << 20;
 
+constexpr uint32_t kTreeFormatGlobal = 0, kTreeFormatPacked = 1, kTreeFormatQuad = 2;
+
 // Kernel arguments of one trace launch.  `params` is the reference's uniform
 // block (raytrace.comp.glsl:19-31) passed by value, so it lands in scalar
 // registers; params.frame_sample_depth_count[0] is ignored in favour of
@@ -34,9 +36,16 @@ struct TraceArgs {
     const uint32_t* tree_word;    // one packed word per node, or two words per node (tree_packed == 0)
     const float4* loop_geom;      // (centre, radius^2) per sphere in global memory, for scenes beyond kMaxSpheresGeomLds without a hierarchy
     uint32_t* unit_counter;       // one word the hierarchy kernel hands out its units from (zeroed by launch_trace)
-    uint32_t tree_nodes;          // 0 = test every sphere
-    uint32_t tree_packed;         // the hierarchy fits LDS and the packed word; otherwise it is walked in global memory,
-                                  // and both node arrays hold one more (unused) entry than tree_nodes
+    uint32_t tree_nodes;          // 0 = test every sphere; nodes of the depth-first tree, or groups of the four-way tree
+    uint32_t tree_packed;         // kTreeFormat*: 1 = the depth-first tree fits LDS and the packed word; 0 = it is walked in
+                                  // global memory, and both node arrays hold one more (unused) entry than tree_nodes;
+                                  // 2 = the complete four-way tree (rt_tree.hpp: QuadTree) in LDS: tree_geom holds four
+                                  // float4 per group, tree_word is unused, and `spheres` is the copy of the sphere list in
+                                  // slot order (one record per slot of the last level and the prologue, the sphere's
+                                  // index in the bits of albedo[3], 0xFFFFFFFF for an unused slot)
+    uint32_t quad_roots;          // four-way tree: groups on level 0,
+    uint32_t quad_first_leaf;     // index of the first group of the last level,
+    uint32_t quad_prologue;       // and whether the group behind the tree (index tree_nodes - 1) holds spheres
     uint32_t scene_bounded;       // every sphere finite with |centre| <= 2^20 and |radius| <= 2^20
     uint32_t width;
     uint32_t height;

@@ -164,17 +164,14 @@ struct Builder {
     }
 };
 
-} // namespace
 
-bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree& out)
+// The spheres as the builders see them; false when the scene does not qualify for a hierarchy.
+bool collect_items(const rt_gpu_sphere* spheres, uint32_t count, std::vector<Item>& items)
 {
-    out.clear();
     if (spheres == nullptr || count < kTreeMinSpheres || count > kTreeMaxSpheres) {
         return false;
     }
-    Builder b;
-    b.out = &out;
-    b.items.resize(count);
+    items.resize(count);
     for (uint32_t i = 0; i < count; ++i) {
         const float* cr = spheres[i].center_radius;
         const float r2 = cr[3] * cr[3];
@@ -182,13 +179,187 @@ bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree&
             if (!(std::fabs(cr[k]) <= 0x1p20f)) {
                 return false; // also rejects NaN
             }
-            b.items[i].c[k] = cr[k];
+            items[i].c[k] = cr[k];
         }
         if (!(r2 >= 0x1p-40f && r2 <= 0x1p40f)) {
             return false;
         }
-        b.items[i].r = std::sqrt(static_cast<double>(r2)) * (1.0 + 1e-9);
-        b.items[i].index = i;
+        items[i].r = std::sqrt(static_cast<double>(r2)) * (1.0 + 1e-9);
+        items[i].index = i;
+    }
+    return true;
+}
+
+// Builder of the complete four-way tree (rt_tree.hpp).
+struct QuadBuilder {
+    Builder balls;   // its items and its bounding_ball()
+    QuadTree* out;
+    const rt_gpu_sphere* spheres;
+
+    // Reorders items[lo, hi) so that the `count` first ones are the lowest along the longest axis of the
+    // centres' bounding box (ties by sphere index, so that the result does not depend on the input order).
+    void split_at(uint32_t lo, uint32_t hi, uint32_t count)
+    {
+        if (count == 0 || lo + count >= hi) {
+            return;
+        }
+        std::vector<Item>& items = balls.items;
+        double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+        for (uint32_t i = lo; i < hi; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = std::min(mn[k], items[i].c[k]);
+                mx[k] = std::max(mx[k], items[i].c[k]);
+            }
+        }
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) {
+            if (mx[k] - mn[k] > mx[axis] - mn[axis]) {
+                axis = k;
+            }
+        }
+        std::nth_element(items.begin() + lo, items.begin() + lo + count, items.begin() + hi, [&](const Item& a, const Item& b) {
+            return a.c[axis] != b.c[axis] ? a.c[axis] < b.c[axis] : a.index < b.index;
+        });
+    }
+
+    void set_slot(uint32_t group, uint32_t k, const float g[4])
+    {
+        std::copy(g, g + 4, out->geom.begin() + (static_cast<size_t>(group) * 4u + k) * 4u);
+    }
+
+    void fill_leaf_group(uint32_t group, uint32_t lo, uint32_t hi)
+    {
+        for (uint32_t i = lo; i < hi; ++i) {
+            const float* cr = spheres[balls.items[i].index].center_radius;
+            const float g[4] = { cr[0], cr[1], cr[2], cr[3] * cr[3] }; // the product the loop over all spheres uses
+            set_slot(group, i - lo, g);
+            out->slot_sphere[4u * (group - out->first_leaf) + (i - lo)] = balls.items[i].index;
+        }
+    }
+
+    // items[lo, hi) go below group `group` of level `level`.
+    void fill_group(uint32_t group, uint32_t level, uint32_t lo, uint32_t hi)
+    {
+        if (level + 1u == out->levels) {
+            fill_leaf_group(group, lo, hi);
+            return;
+        }
+        const uint32_t m = hi - lo;
+        uint32_t cut[5];
+        cut[0] = lo;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            cut[k + 1u] = cut[k] + m / 4u + (k < m % 4u ? 1u : 0u);
+        }
+        split_at(lo, hi, cut[2] - lo);
+        split_at(lo, cut[2], cut[1] - lo);
+        split_at(cut[2], hi, cut[3] - cut[2]);
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (cut[k + 1u] > cut[k]) {
+                float g[4];
+                balls.bounding_ball(cut[k], cut[k + 1u], g);
+                set_slot(group, k, g);
+                fill_group(4u * group + out->roots + k, level + 1u, cut[k], cut[k + 1u]);
+            }
+        }
+    }
+
+    // items[lo, hi) are shared out over the root groups [first, first + count).
+    void fill_roots(uint32_t first, uint32_t count, uint32_t lo, uint32_t hi)
+    {
+        if (count == 1u) {
+            fill_group(first, 0u, lo, hi);
+            return;
+        }
+        const uint32_t left = count / 2u;
+        const uint32_t m = hi - lo;
+        const uint32_t m_left = static_cast<uint32_t>(static_cast<uint64_t>(m) * left / count);
+        split_at(lo, hi, m_left);
+        fill_roots(first, left, lo, lo + m_left);
+        fill_roots(first + left, count - left, lo + m_left, hi);
+    }
+};
+
+} // namespace
+
+bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out)
+{
+    out.clear();
+    QuadBuilder b;
+    b.out = &out;
+    b.spheres = spheres;
+    b.balls.out = nullptr;
+    std::vector<Item>& items = b.balls.items;
+    if (!collect_items(spheres, count, items)) {
+        return false;
+    }
+    // Spheres more than sixteen times the median radius: the (up to four) largest go into the prologue.
+    std::vector<double> radii(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        radii[i] = items[i].r;
+    }
+    std::nth_element(radii.begin(), radii.begin() + count / 2u, radii.end());
+    const double big = 16.0 * radii[count / 2u];
+    std::stable_sort(items.begin(), items.end(), [&](const Item& x, const Item& y) {
+        const bool bx = x.r > big, by = y.r > big;
+        return bx != by ? bx : (bx && x.r != y.r ? x.r > y.r : false);
+    });
+    uint32_t outliers = 0;
+    while (outliers < 4u && outliers < count && items[outliers].r > big) {
+        ++outliers;
+    }
+    const uint32_t in_tree = count - outliers;
+    // Shape: the fewest groups on the last level for up to kQuadMaxRoots roots; of equal ones the fewer roots.
+    const uint64_t leaf_groups_needed = (static_cast<uint64_t>(in_tree) + 3u) / 4u;
+    uint64_t best_leaf_groups = 0;
+    uint64_t per_root = 1; // groups of the last level below one root
+    for (uint32_t levels = 1; levels <= kQuadMaxLevels + 1u; ++levels, per_root *= 4u) {
+        const uint64_t roots = (leaf_groups_needed + per_root - 1u) / per_root;
+        if (roots > kQuadMaxRoots) {
+            continue;
+        }
+        const uint64_t leaf_groups = roots * per_root;
+        if (out.levels == 0 || leaf_groups < best_leaf_groups || (leaf_groups == best_leaf_groups && roots < out.roots)) {
+            out.levels = levels;
+            out.roots = static_cast<uint32_t>(roots);
+            best_leaf_groups = leaf_groups;
+        }
+        if (roots <= 1u) {
+            break;
+        }
+    }
+    if (out.levels == 0) {
+        out.clear();
+        return false;
+    }
+    uint64_t per_level = out.roots, tree_groups = 0, first_leaf = 0;
+    for (uint32_t l = 0; l < out.levels; ++l, per_level *= 4u) {
+        first_leaf = tree_groups;
+        tree_groups += per_level;
+    }
+    if (tree_groups + 1u > kQuadMaxGroups) {
+        out.clear();
+        return false;
+    }
+    out.first_leaf = static_cast<uint32_t>(first_leaf);
+    out.has_prologue = outliers != 0;
+    const float unused[4] = { 0.0f, 0.0f, 0.0f, -INFINITY };
+    out.geom.resize((tree_groups + 1u) * 16u);
+    for (size_t slot = 0; slot < out.geom.size() / 4u; ++slot) {
+        std::copy(unused, unused + 4, out.geom.begin() + slot * 4u);
+    }
+    out.slot_sphere.assign((tree_groups + 1u - first_leaf) * 4u, kTreeNoSphere);
+    b.fill_leaf_group(static_cast<uint32_t>(tree_groups), 0u, outliers); // the prologue sits behind the tree
+    b.fill_roots(0u, out.roots, outliers, count);
+    return true;
+}
+
+bool build_sphere_tree(const rt_gpu_sphere* spheres, uint32_t count, SphereTree& out)
+{
+    out.clear();
+    Builder b;
+    b.out = &out;
+    if (!collect_items(spheres, count, b.items)) {
+        return false;
     }
     b.emit_children(0, count, spheres);
     const uint32_t nodes = out.node_count();

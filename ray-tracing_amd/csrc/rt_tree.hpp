@@ -74,6 +74,49 @@ struct SphereTree {
     }
 };
 
+// ---- the same hierarchy as a complete four-way tree, for scenes whose tree fits LDS ------------------------
+// Groups of four balls, visited one group per trip of the walk: the four tests are independent, so their four
+// LDS reads are in flight together and a segment's chain of dependent reads is a quarter as long as with one node
+// per trip.  The tree is complete and implicit: `roots` groups on level 0, four times as many on each level
+// below, `levels` levels; group g of the tree has the children 4 g + roots + k (k = 0..3) and the parent
+// (g - roots) / 4, so no links are stored.  A group above the last level holds the inflated bounding balls of its
+// four child groups (w = 1.125 R^2 rounded up, tested with dot(oc,oc) scaled by 1 - 2^-13, as in the tree above);
+// a group of the last level holds four spheres, (centre, radius^2), tested with hitSphere's own arithmetic.  An
+// unused slot has w = -infinity, which no ray passes.  Spheres are dealt out evenly (every split is at the
+// median count, along the longest axis of the part's centres), so the depth of every sphere is the same.
+// Spheres far larger than the rest (the ground under a field of small spheres) would inflate every ball above
+// them; up to four of them are kept out of the tree in one more group of the last-level kind, the prologue,
+// stored behind the tree (group index group_count - 1) and visited first by every ray.
+// slot_sphere[4 (g - first_leaf) + k] is the sphere in slot k of last-level group g (the prologue included).
+struct QuadTree {
+    uint32_t levels = 0;      // 0: no tree
+    uint32_t roots = 0;       // groups on level 0, 1..kQuadMaxRoots
+    uint32_t first_leaf = 0;  // index of the first group of the last level
+    bool has_prologue = false;
+    std::vector<float> geom;           // 16 floats per group: tree groups level by level, then the prologue
+    std::vector<uint32_t> slot_sphere; // kTreeNoSphere for an unused slot
+    uint32_t group_count() const { return static_cast<uint32_t>(geom.size() / 16u); }
+    uint32_t slot_count() const { return static_cast<uint32_t>(slot_sphere.size()); }
+    bool empty() const { return levels == 0; }
+    void clear()
+    {
+        levels = roots = first_leaf = 0;
+        has_prologue = false;
+        geom.clear();
+        slot_sphere.clear();
+    }
+};
+constexpr uint32_t kQuadMaxRoots = 16;
+// Most groups a four-way tree kept in LDS may have: 64 bytes per group plus the hash tables of sixteen waves
+// within the 160 KiB of a compute unit.
+constexpr uint32_t kQuadMaxGroups = 2440;
+// Levels below the roots the walk's stack of pending-sibling masks (four bits per level in one register) holds.
+constexpr uint32_t kQuadMaxLevels = 9;
+
+// Builds the four-way tree for the scenes build_sphere_tree accepts; returns false (and leaves `out` empty) for the
+// others and for trees of more than kQuadMaxGroups groups.
+bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out);
+
 // Builds the hierarchy.  Returns false (and leaves `out` empty) when the scene does not qualify:
 // fewer than kTreeMinSpheres or more than kTreeMaxSpheres spheres, or any centre/radius outside the
 // ranges the error bounds were derived for (non-finite values, |centre| > 2^20, radius^2 outside

@@ -63,6 +63,9 @@ ABI = {
     "rt_get_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.POINTER(_U32)]),
     "rt_get_scene_hierarchy_links": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _U32,
                                                     ctypes.POINTER(_U32)]),
+    "rt_get_scene_quadtree": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, _U32, ctypes.POINTER(_U32),
+                                             ctypes.POINTER(_U32), ctypes.POINTER(_U32), ctypes.POINTER(_U32),
+                                             ctypes.POINTER(_U32), ctypes.POINTER(ctypes.c_int)]),
     "rt_set_frame_overlap": (ctypes.c_int, [_H, ctypes.c_int]),
     "rt_get_params": (ctypes.c_int, [_H, _U32, ctypes.POINTER(GPUParams)]),
     "rt_reset_accumulation": (ctypes.c_int, [_H]),
@@ -229,8 +232,24 @@ class RayTracer:
 
     def set_scene_hierarchy(self, enable):
         """Scenes of 24 spheres or more are traced through a bounding-sphere hierarchy (same images);
-        enable=False tests every sphere against every ray like the shader's loop (raytrace.comp.glsl:247-259)."""
-        self._check(self._lib.rt_set_scene_hierarchy(self._h, 1 if enable else 0))
+        enable=False tests every sphere against every ray like the shader's loop (raytrace.comp.glsl:247-259);
+        enable=2 walks the depth-first tree, one node per step, also where the four-way tree would be used."""
+        self._check(self._lib.rt_set_scene_hierarchy(self._h, int(enable) if enable in (0, 1, 2) else (1 if enable else 0)))
+
+    def get_scene_quadtree(self):
+        """The current scene's complete four-way tree: dict(geom (groups, 4, 4) float32, slot_sphere (slots,) uint32,
+        levels, roots, first_leaf, has_prologue); geom has no groups when the scene has no such tree."""
+        n_groups, n_slots, levels, roots, first_leaf = _U32(), _U32(), _U32(), _U32(), _U32()
+        prologue = ctypes.c_int()
+        refs = [ctypes.byref(v) for v in (n_groups, n_slots, levels, roots, first_leaf, prologue)]
+        self._check(self._lib.rt_get_scene_quadtree(self._h, None, None, 0, 0, *refs))
+        geom = np.zeros((n_groups.value, 4, 4), dtype=np.float32)
+        slot_sphere = np.zeros((n_slots.value,), dtype=np.uint32)
+        if n_groups.value:
+            self._check(self._lib.rt_get_scene_quadtree(self._h, geom.ctypes.data, slot_sphere.ctypes.data, n_groups.value,
+                                                        n_slots.value, *refs))
+        return {"geom": geom, "slot_sphere": slot_sphere, "levels": levels.value, "roots": roots.value,
+                "first_leaf": first_leaf.value, "has_prologue": bool(prologue.value)}
 
     def set_frame_overlap(self, enable):
         """Consecutive single-frame calls overlap on the GPU (default); False keeps every launch on the

@@ -58,7 +58,9 @@ def _case(seed, specials=False, big=False):
             "focus": float(10.0 ** rng.uniform(-1.0, 2.0)),
             "pattern": str(rng.choice(["batch", "calls", "stripes"])),
             "ranks": int(rng.integers(1, 4)), "stripe_rows": int(rng.choice([1, 2, 4, 8])),
-            "hierarchy": bool(rng.random() < 0.6),
+            # 0: the loop over all spheres; 1: the hierarchy as the library walks it by default (the four-way tree
+            # where it fits LDS); 2: the depth-first tree, one node per step
+            "hierarchy": (1 + seed % 2) if rng.random() < 0.6 else 0,
         }
     return {
         "scene": scene,
@@ -72,6 +74,7 @@ def _case(seed, specials=False, big=False):
         # library's two streams), or as the interleaved stripe shards of several ranks
         "pattern": str(rng.choice(["batch", "batch", "calls", "stripes"])),
         "ranks": int(rng.integers(1, 6)), "stripe_rows": int(rng.choice([1, 2, 3, 4, 8, 16])),
+        "hierarchy": 2 if seed % 3 == 0 else 1,
     }
 
 
@@ -97,8 +100,7 @@ def _run_case(pkg, oracle, c):
     t.set_aperture(c["aperture"])
     t.set_fov(c["fov"])
     t.set_spheres(c["scene"])
-    if not c.get("hierarchy", True):
-        t.set_scene_hierarchy(False)
+    t.set_scene_hierarchy(int(c.get("hierarchy", 1)))
     target = c["scene"][len(c["scene"]) // 2, 0:3]
     direction = target - c["pos"]
     if not np.any(direction != 0.0):

@@ -308,7 +308,8 @@ def test_frame_stride_shards(pkg, oracle):
 
 
 @pytest.mark.parametrize("count,hierarchy", [(2, True), (23, True), (24, True), (24, False), (63, True), (64, True), (64, False), (1024, True), (1024, False),
-                                             (1500, True), (1500, False), (4096, True), (4096, False)])
+                                             (1500, True), (1500, False), (4096, True), (4096, False),
+                                             (24, 2), (64, 2), (1024, 2), (4096, 2), (65, True), (257, True), (4097, True)])
 def test_custom_scenes(pkg, oracle, count, hierarchy):
     # with the hierarchy off, 1500 and 4096 spheres exercise the geometry-only LDS layout of the loop
     # over all spheres (materials fetched from global memory); with it on, scenes of 24 spheres or

@@ -309,6 +309,180 @@ def test_walk_finds_the_hit_of_the_loop_over_all_spheres(pkg, name):
     assert visits < 0.25 * rays * len(word)    # node visits, inner nodes included
 
 
+# ------------------------------------------------------------------------ the four-way tree
+NONE = 0xFFFFFFFF
+
+
+def _quad(pkg, scene):
+    t = _host(pkg, scene)
+    q = t.get_scene_quadtree()
+    t.destroy()
+    return q
+
+
+def _check_quad_structure(scene, q):
+    geom, slot_sphere = q["geom"], q["slot_sphere"]
+    groups, levels, roots, first_leaf = len(geom), q["levels"], q["roots"], q["first_leaf"]
+    assert levels >= 1 and 1 <= roots <= 16
+    per_level = [roots * 4 ** l for l in range(levels)]
+    assert groups == sum(per_level) + 1                          # the tree, then the prologue
+    assert first_leaf == sum(per_level[:-1])
+    assert len(slot_sphere) == 4 * (groups - first_leaf)
+    used = slot_sphere != NONE
+    assert sorted(slot_sphere[used].tolist()) == list(range(len(scene)))     # every sphere in exactly one slot
+    leaf_geom = geom[first_leaf:].reshape(-1, 4)
+    s = scene[slot_sphere[used]]
+    assert np.array_equal(leaf_geom[used, :3], s[:, :3])
+    assert np.array_equal(leaf_geom[used, 3], s[:, 3] * s[:, 3])             # the float product the loop uses
+    assert np.all(np.isneginf(leaf_geom[~used, 3]))
+    assert q["has_prologue"] == bool(used[-4:].any())
+    # spheres are dealt out evenly: the groups of the last level differ by at most one sphere
+    per_group = used[:-4].reshape(-1, 4).sum(1)
+    assert per_group.max() - per_group.min() <= 1 and per_group.max() >= 1
+
+    def spheres_below(g, level):
+        if level == levels - 1:
+            return [int(x) for x in slot_sphere[4 * (g - first_leaf):4 * (g - first_leaf) + 4] if x != NONE]
+        out = []
+        for k in range(4):
+            below = spheres_below(4 * g + roots + k, level + 1)
+            ball = geom[g, k]
+            if not below:
+                assert np.isneginf(ball[3])
+                continue
+            centre = ball[:3].astype(np.float64)
+            radius = np.sqrt(float(ball[3]) / 1.125)
+            c = scene[below, :3].astype(np.float64)
+            r = scene[below, 3].astype(np.float64)
+            assert np.all(np.sqrt(((c - centre) ** 2).sum(1)) + r <= radius * (1.0 + 1e-6))
+            out += below
+        return out
+
+    in_tree = []
+    for root in range(roots):
+        in_tree += spheres_below(root, 0)
+    assert sorted(in_tree + [int(x) for x in slot_sphere[-4:] if x != NONE]) == list(range(len(scene)))
+
+
+@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "synthetic24", "synthetic4097", "random", "clusters"])
+def test_quadtree_structure(pkg, name):
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "synthetic100": lambda: pkg.synthetic_scene(100),
+             "synthetic24": lambda: pkg.synthetic_scene(24), "synthetic4097": lambda: pkg.synthetic_scene(4097),
+             "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
+    q = _quad(pkg, scene)
+    assert 0 < len(q["geom"]) <= 2440
+    _check_quad_structure(scene, q)
+    q2 = _quad(pkg, scene)
+    assert np.array_equal(q["geom"].view(np.uint32), q2["geom"].view(np.uint32)) and np.array_equal(q["slot_sphere"], q2["slot_sphere"])
+    if name == "synthetic4096":
+        # the ground sphere is kept out of the tree; 4095 spheres fill 1024 groups of the sixth level
+        assert q["has_prologue"] and q["slot_sphere"][-4] == 0 and q["levels"] == 6 and q["roots"] == 1
+
+
+def test_scenes_without_quadtree(pkg):
+    t = pkg.RayTracer().create(64, 64, device_id=-1)
+    assert len(t.get_scene_quadtree()["geom"]) == 0           # the default five spheres
+    t.set_spheres(pkg.synthetic_scene(23))
+    assert len(t.get_scene_quadtree()["geom"]) == 0
+    scene = pkg.synthetic_scene(200)
+    scene[77, 0] = np.nan
+    t.set_spheres(scene)
+    assert len(t.get_scene_quadtree()["geom"]) == 0
+    t.set_spheres(pkg.synthetic_scene(9000))                  # does not fit LDS: only the depth-first tree exists
+    assert len(t.get_scene_quadtree()["geom"]) == 0
+    assert len(t.get_scene_hierarchy_links()[1]) > 0
+    t.destroy()
+
+
+def _quad_walk_closest(q, scene, o, d):
+    """The kernel's walk of the four-way tree in float32, ray by ray: four balls per visited group, pending siblings
+    as four bits per level, spheres resolved in slot order with ties going to the higher sphere index."""
+    geom, slot_sphere = q["geom"], q["slot_sphere"]
+    roots, first_leaf, groups = q["roots"], q["first_leaf"], len(q["geom"])
+    rays = o.shape[0]
+    out_closest = np.full(rays, 1e20, dtype=np.float32)
+    out_best = np.full(rays, -1, dtype=np.int64)
+    visits = 0
+    for ray in range(rays):
+        ro, rd = o[ray], d[ray]
+        a = _dot(rd, rd)
+        closest, best, limit = F(1e20), -1, F(np.inf)
+        stack = 0
+        root = -1 if q["has_prologue"] else 0
+        grp = groups - 1 if q["has_prologue"] else 0
+        while grp is not None:
+            visits += 1
+            balls = geom[grp]
+            leaf = grp >= first_leaf
+            scale = F(1.0) if leaf else KEEP
+            with np.errstate(invalid="ignore", over="ignore"):
+                hb, c, disc = _quadratic(balls[:, :3], balls[:, 3], ro[None, :], rd[None, :], a, scale)
+                ok = _passes(hb, c, disc) & ~(c - balls[:, 3] > limit)
+            if leaf:
+                for k in np.nonzero(ok)[0]:
+                    with np.errstate(invalid="ignore", over="ignore"):
+                        root_t, found = _roots(hb[k:k + 1], disc[k:k + 1], a, F(0.001), closest)
+                    if not found[0]:
+                        continue
+                    slot = 4 * (grp - first_leaf) + int(k)
+                    if root_t[0] < closest or best < 0 or slot_sphere[slot] > slot_sphere[best]:
+                        closest, best = root_t[0], slot
+                    limit = F(2.5) * a * closest * closest
+                ok[:] = False
+            mask = int(sum(1 << k for k in range(4) if ok[k]))
+            if mask:
+                k = (mask & -mask).bit_length() - 1
+                stack = (stack << 4) | (mask & (mask - 1))
+                assert stack < 2 ** 32
+                grp = 4 * grp + roots + k
+            elif stack == 0:
+                root += 1
+                grp = root if root < roots else None
+            else:
+                up = ((stack & -stack).bit_length() - 1) >> 2
+                stack >>= 4 * up
+                for _ in range(up):
+                    grp = (grp - roots) >> 2
+                k = (stack & -stack).bit_length() - 1
+                stack &= stack - 1
+                grp = ((grp - roots) & ~3) + roots + k
+        out_closest[ray] = closest
+        out_best[ray] = -1 if best < 0 else int(slot_sphere[best])
+    return out_closest, out_best, visits
+
+
+@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "random", "clusters"])
+def test_quad_walk_finds_the_hit_of_the_loop_over_all_spheres(pkg, name):
+    """The walk of the four-way tree ends with the same root and the same sphere as the loop of :247-259
+    (smallest accepted root; of equal roots the highest index), for camera-like, surface-born, far-away and
+    grazing rays of assorted lengths."""
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "synthetic100": lambda: pkg.synthetic_scene(100),
+             "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
+    q = _quad(pkg, scene)
+    rays = 400 if name == "synthetic4096" else 800
+    o, d = _rays(scene, rays, seed=29)
+    a = _dot(d, d)
+    closest, best, visits = _quad_walk_closest(q, scene, o, d)
+    centre = scene[:, :3]
+    r2 = scene[:, 3] * scene[:, 3]
+    hits = 0
+    for lo in range(0, rays, 200):
+        sl = slice(lo, lo + 200)
+        hb, c, disc = _quadratic(centre[None, :, :], r2[None, :], o[sl, None, :], d[sl, None, :], a[sl, None], F(1.0))
+        root, found = _roots(hb, disc, a[sl, None], F(0.001), F(1e20))
+        root = np.where(found, root, F(np.inf))
+        want_closest = root.min(axis=1)
+        any_hit = np.isfinite(want_closest)
+        ties = root == want_closest[:, None]
+        want_best = np.where(any_hit, len(scene) - 1 - np.argmax(ties[:, ::-1], axis=1), -1)
+        want_closest = np.where(any_hit, want_closest, F(1e20)).astype(np.float32)
+        assert np.array_equal(best[sl], want_best)
+        assert np.array_equal(closest[sl].view(np.uint32), want_closest.view(np.uint32))
+        hits += int(any_hit.sum())
+    assert hits > rays // 2
+    assert visits < (0.1 if len(scene) > 1000 else 0.6) * rays * len(q["geom"])       # group visits: the walk does prune
+
+
 # ---------------------------------------------------------------------------------------- GPU
 def _render(pkg, scene, hierarchy, w=160, h=96, spp=4, depth=12, frames=3, camera=None, focus=6.0, aperture=0.05):
     t = pkg.RayTracer().create(w, h, device_id=0)
@@ -334,15 +508,18 @@ def test_hierarchy_matches_loop_on_gpu(pkg, name):
     camera = ([13.0, 2.0, 3.0], [-13.0, -1.0, -3.0]) if name == "random" else None
     if name == "clusters":
         camera = ([0.0, 4.0, 30.0], [0.0, -0.1, -1.0])
-    a = _render(pkg, scene, True, camera=camera)
-    b = _render(pkg, scene, False, camera=camera)
-    for x, y in zip(a, b):
+    a = _render(pkg, scene, True, camera=camera)      # the four-way tree (all four scenes fit LDS)
+    b = _render(pkg, scene, False, camera=camera)     # the loop over all spheres
+    c = _render(pkg, scene, 2, camera=camera)         # the depth-first tree, one node per step
+    for x, y, z in zip(a, b, c):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert np.array_equal(z.view(np.uint8), y.view(np.uint8))
     assert np.any(a[0][..., :3] > 0.0)
 
 
 @pytest.mark.gpu
-def test_hierarchy_ties_and_oracle(pkg, oracle):
+@pytest.mark.parametrize("walk", [1, 2])
+def test_hierarchy_ties_and_oracle(pkg, oracle, walk):
     """Coincident spheres give exactly equal roots; the later index must win as in the shader's loop."""
     from test_gpu_parity import oracle_frames, same
     scene = _cluster_scene(pkg, count=120)
@@ -350,6 +527,7 @@ def test_hierarchy_ties_and_oracle(pkg, oracle):
     t.set_samples_per_pixel(2)
     t.set_max_depth(8)
     t.set_spheres(scene)
+    t.set_scene_hierarchy(walk)
     t.set_camera([0.0, 4.0, 30.0], [0.0, -0.1, -1.0], 30.0)
     t.enable_rng_capture(True)
     assert len(t.get_scene_hierarchy()[1]) > 0
@@ -361,11 +539,13 @@ def test_hierarchy_ties_and_oracle(pkg, oracle):
 
 
 @pytest.mark.gpu
-def test_rays_outside_the_proven_range_use_the_loop(pkg):
+@pytest.mark.parametrize("walk", [1, 2])
+def test_rays_outside_the_proven_range_use_the_loop(pkg, walk):
     """A focus distance of 4000 makes the camera rays' dot(d,d) exceed 2^20: those rays must take the
     plain loop inside the hierarchy kernel, and the image must not change."""
     scene = pkg.synthetic_scene(500)
-    a = _render(pkg, scene, True, focus=4000.0, aperture=0.0)
+    scene[100:110, :4] = scene[110:120, :4]       # coincident spheres: ties inside that loop as well
+    a = _render(pkg, scene, walk, focus=4000.0, aperture=0.0)
     b = _render(pkg, scene, False, focus=4000.0, aperture=0.0)
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
@@ -379,8 +559,10 @@ def test_hierarchy_unit_boundaries(pkg, w, h, frames, spp):
     scene = pkg.synthetic_scene(300)
     a = _render(pkg, scene, True, w=w, h=h, spp=spp, depth=6, frames=frames)
     b = _render(pkg, scene, False, w=w, h=h, spp=spp, depth=6, frames=frames)
-    for x, y in zip(a, b):
+    c = _render(pkg, scene, 2, w=w, h=h, spp=spp, depth=6, frames=frames)
+    for x, y, z in zip(a, b, c):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert np.array_equal(z.view(np.uint8), y.view(np.uint8))
 
 
 @pytest.mark.gpu
@@ -495,8 +677,10 @@ def test_4096_spheres_at_full_size(pkg):
     scene = pkg.synthetic_scene(4096)
     a = _render(pkg, scene, True, w=1920, h=1080, spp=16, depth=50, frames=1)
     b = _render(pkg, scene, False, w=1920, h=1080, spp=16, depth=50, frames=1)
-    for x, y in zip(a, b):
+    c = _render(pkg, scene, 2, w=1920, h=1080, spp=16, depth=50, frames=1)
+    for x, y, z in zip(a, b, c):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert np.array_equal(z.view(np.uint8), y.view(np.uint8))
 
 
 @pytest.mark.gpu
@@ -514,7 +698,27 @@ def test_largest_tree_kept_in_lds(pkg):
         nodes = len(t.get_scene_hierarchy_links()[1])
     assert nodes > 7600 and len(t.get_scene_hierarchy()[1]) == nodes      # packed
     t.destroy()
-    a = _render(pkg, scene, True, w=64, h=40, spp=1, depth=4, frames=2)
+    a = _render(pkg, scene, 2, w=64, h=40, spp=1, depth=4, frames=2)
     b = _render(pkg, scene, False, w=64, h=40, spp=1, depth=4, frames=2)
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_largest_four_way_tree_kept_in_lds(pkg):
+    """The largest scene whose four-way tree still fits LDS (close to 2440 groups of 64 bytes beside the hash
+    tables of sixteen waves), and the first one beyond, which falls back to the depth-first tree."""
+    count = 7300
+    t = _host(pkg, pkg.synthetic_scene(count))
+    while len(t.get_scene_quadtree()["geom"]) == 0:
+        count -= 100
+        t.set_spheres(pkg.synthetic_scene(count))
+    groups = len(t.get_scene_quadtree()["geom"])
+    assert 2000 < groups <= 2440
+    t.destroy()
+    for n in (count, count + 100):
+        scene = pkg.synthetic_scene(n)
+        a = _render(pkg, scene, True, w=64, h=40, spp=1, depth=4, frames=2)
+        b = _render(pkg, scene, False, w=64, h=40, spp=1, depth=4, frames=2)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))

@@ -205,6 +205,10 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the multi-GPU code path (process group, collective, resolve) even with one rank")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--collectives", choices=["native", "torch"], default="native",
+                    help="native: the library's own RCCL entry points (librt_mi355x_rccl.so: hand-written pack / unpack kernels "
+                         "around ncclAllGather / ncclAllReduce on a communicator of its own), used whenever the backend is nccl; "
+                         "torch: torch.distributed collectives and strided tensor copies (always used with gloo and in rehearsals)")
     ap.add_argument("--watchdog", type=int, default=300,
                     help="seconds after which a rank that is still running prints its Python stacks and exits (0 = off)")
     ap.add_argument("--same-device", action="store_true",
@@ -288,6 +292,10 @@ def main():
         tracer.set_frame_overlap(False)
 
     stripe_rows = args.stripe_rows or (16 if height >= 4000 else 4)
+    native = None
+    if distributed and not rehearse and args.backend == "nccl" and args.collectives == "native":
+        from raytracing_amd import rccl as rtrccl
+        native = rtrccl.Communicator(rtrccl.unique_id_over_torch(rank, device), world, rank, device_id=device_index)
     accum = rtdist.accum_tensor(tracer, device) if distributed else None
     # The collective of a step runs on a side stream, and the rendering stream never waits for that stream: the
     # rank's shard is copied out of the accumulator on the rendering stream itself (into one of two staging
@@ -310,6 +318,33 @@ def main():
         slot = index % 2
         if collected[slot] is not None:
             collected[slot].synchronize()      # host: the collective of two steps ago has read this staging buffer
+        if native is not None:
+            # the same pipeline through the library's own entry points: the shard is packed (or the accumulator
+            # staged) on the rendering stream, the collective, the unpacking and the resolve run on the side stream
+            if args.mode == "tiles":
+                tracer.render_stripes(base, frames, 1, stripe_rows, rank, world, write_output=False)
+                native.pack_stripes(tracer, stripe_rows, slot, stream.cuda_stream)
+            else:
+                count = len(range(rank, frames_per_step, world))
+                if count:
+                    tracer.render_shard(base + rank, count, world, 0, height, write_output=False)
+                native.stage_accum(tracer, slot, stream.cuda_stream)
+            copied = torch.cuda.Event()
+            copied.record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(copied)
+                tracer.set_stream(comm.cuda_stream)
+                if args.mode == "tiles":
+                    native.gather_packed(tracer, stripe_rows, slot, image.data_ptr(), comm.cuda_stream)
+                    shown_ptr = image.data_ptr()
+                else:
+                    shown_ptr = native.reduce_staged(tracer, slot, comm.cuda_stream)
+                    staging[slot] = shown_ptr
+                tracer.resolve_output_from(shown_ptr, (base + frames_per_step) * spp)
+                tracer.set_stream(stream.cuda_stream)
+                collected[slot] = torch.cuda.Event()
+                collected[slot].record(comm)
+            return
         if args.mode == "tiles":
             # rank r: stripes r, r + world, ... of every frame of the step
             tracer.render_stripes(base, frames, 1, stripe_rows, split_rank, split_world, write_output=False)
@@ -386,7 +421,12 @@ def main():
     if args.verify and distributed and rank == 0 and not rehearse:
         import numpy as np
         last = (args.warmup + args.steps - 1) % 2
-        together = (staging[last] if (args.mode == "frames" or split_world == 1) else image).cpu().numpy()
+        if native is not None:
+            together = image if args.mode == "tiles" else torch.as_tensor(
+                rtdist.DeviceImage(staging[last], (height, width, 4), "<f4"), device=device)
+            together = together.cpu().numpy()
+        else:
+            together = (staging[last] if (args.mode == "frames" or split_world == 1) else image).cpu().numpy()
         whole = pkg.RayTracer().create(width, height, device_id=device_index)
         whole.set_samples_per_pixel(spp)
         whole.set_max_depth(wl["depth"])
@@ -418,6 +458,8 @@ def main():
         if distributed:
             how = ("interleaved %d-row stripes x%d + RCCL all-gather of the accumulator" % (stripe_rows, split_world)
                    if args.mode == "tiles" else "frame-index split x%d + RCCL sum all-reduce of the accumulator" % split_world)
+            how += (" (librt_mi355x_rccl.so: native pack/unpack kernels, ncclAllGather/ncclAllReduce)" if native is not None
+                    else " (torch.distributed, backend %s)" % args.backend)
             if rehearse:
                 how = ("REHEARSAL ON ONE GPU, not a measurement of %d GPUs: rank 0's part of [%s], the collective replaced by "
                        "device copies of the same size; value = what %d ranks would reach if each took as long"
@@ -497,6 +539,9 @@ def main():
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
 
+    if native is not None:
+        torch.cuda.synchronize(device)
+        native.destroy()
     tracer.destroy()
     if distributed and not rehearse:
         dist.destroy_process_group()

@@ -10,8 +10,12 @@
  * from one thread at a time and from one stream at a time (a call on another
  * stream must be ordered after the handle's earlier work by the caller: the
  * launches of one handle share its accumulator, its per-frame sums and its unit
- * counter); one handle drives one GPU.  A call that fails leaves the handle's
- * extent, images and scene as they were before the call.
+ * counter); one handle drives one GPU.  The one exception: rt_resolve_output_from
+ * reads a caller-owned image and writes the output image only, so it may run on
+ * another stream beside render calls of the same handle that pass
+ * write_output = 0 (a multi-GPU step resolves the gathered image of step i while
+ * step i + 1 renders).  A call that fails leaves the handle's extent, images and
+ * scene as they were before the call.
  *
  * Images are linear row-major, row 0 = top, pitch = width: the accumulator is
  * float4 per pixel (the rgba32f storage image, binding 0), the output is
@@ -245,7 +249,8 @@ size_t rt_static_scratch_bytes(void);
  * (frame + 1) * spp. */
 int rt_resolve_output(rt_handle h, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *stream);
 /* The same, reading a caller-owned float4 image of the handle's extent (e.g. the
- * buffer a multi-GPU sum-reduction of accumulators landed in). */
+ * buffer a multi-GPU sum-reduction of accumulators landed in).  Touches nothing
+ * of the handle but the output image: see the stream rule at the top. */
 int rt_resolve_output_from(rt_handle h, const void *accum_device, uint32_t sample_count, uint32_t row_begin,
                            uint32_t row_end, void *stream);
 

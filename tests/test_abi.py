@@ -26,6 +26,25 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.ABI.keys()) == declared, "Python binding and header disagree"
 
 
+def test_rccl_library_exports_every_declared_symbol(pkg):
+    """The multi-GPU library (include/rt_mi355x_rccl.h) loads without a GPU and exports what its header declares."""
+    from raytracing_amd import rccl
+    text = open(os.path.join(ROOT, "include", "rt_mi355x_rccl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+    assert len(declared) >= 12
+    lib = rccl.load_library()
+    for name in declared:
+        assert hasattr(lib, name), "librt_mi355x_rccl.so does not export %s" % name
+    assert sorted(rccl.ABI.keys()) == declared, "Python binding and header disagree"
+    # bad arguments are reported, not crashed on
+    assert lib.rt_comm_destroy(None) != 0
+    assert lib.rt_comm_world(None) == 0 and lib.rt_comm_rank(None) == -1
+    out = ctypes.c_void_p()
+    assert lib.rt_comm_create(bytes(128), 2, 5, 0, ctypes.byref(out)) != 0
+    assert b"rank outside the world" in lib.rt_comm_last_error(None)
+
+
 def test_struct_layouts(pkg):
     assert ctypes.sizeof(pkg.GPUSphere) == 48
     assert ctypes.sizeof(pkg.GPUParams) == 160

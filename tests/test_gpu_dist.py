@@ -74,6 +74,95 @@ def test_rccl_leg_on_a_one_rank_group(pkg, oracle):
         dist.destroy_process_group()
 
 
+def test_native_rccl_entry_points_on_a_one_rank_communicator(pkg, oracle):
+    """The collectives behind the C ABI (librt_mi355x_rccl.so: hand-written pack / unpack kernels around
+    ncclAllGather and ncclAllReduce) on a one-rank communicator of the library's own: the same checks as
+    test_rccl_leg_on_a_one_rank_group makes of the torch.distributed path, bit for bit."""
+    import torch
+    from raytracing_amd import rccl
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    comm = rccl.Communicator(rccl.unique_id(), 1, 0, device_id=0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    t = make_tracer(pkg, W, H, SPP, DEPTH)
+    t.set_stream(stream)
+    ref = oracle_frames(oracle, t, pkg.default_scene(), range(FRAMES))
+    # frame split: the (one-rank) sum into a second buffer, alpha back to 1
+    t.render_shard(0, FRAMES, 1, 0, H, write_output=False)
+    bad_alpha = t.read_accum()
+    bad_alpha[..., 3] = 5.0
+    t.write_accum(bad_alpha)
+    reduced = torch.empty((H, W, 4), dtype=torch.float32, device=device)
+    comm.reduce_frames(t, reduced.data_ptr(), stream)
+    torch.cuda.synchronize(device)
+    assert same(reduced.cpu().numpy(), ref["accum"])
+    t.resolve_output_from(reduced.data_ptr(), FRAMES * SPP)
+    assert same(t.read_output(), ref["output"])
+    # ... in place, and through the two halves a pipelined caller uses
+    comm.reduce_frames(t, t.accum_device_ptr(), stream)
+    assert same(t.read_accum(), ref["accum"])
+    t.write_accum(bad_alpha)
+    comm.stage_accum(t, 1, stream)
+    staged = comm.reduce_staged(t, 1, stream)
+    t.resolve_output_from(staged, FRAMES * SPP)
+    assert same(t.read_output(), ref["output"])
+    # stripes: pack, all-gather, unpack -- heights that are no multiple of the stripe, in place and into a second image
+    for stripe_rows in (4, 7, 64, 1000):
+        t.reset_accumulation()
+        t.render_stripes(0, FRAMES, 1, stripe_rows, 0, 1, write_output=False)
+        image = torch.full((H, W, 4), 3.0, dtype=torch.float32, device=device)
+        comm.gather_stripes(t, stripe_rows, image.data_ptr(), stream)
+        torch.cuda.synchronize(device)
+        assert same(image.cpu().numpy(), ref["accum"])
+        comm.gather_stripes(t, stripe_rows, t.accum_device_ptr(), stream)
+        assert same(t.read_accum(), ref["accum"])
+    comm.pack_stripes(t, 4, 1, stream)
+    image.fill_(0.0)
+    comm.gather_packed(t, 4, 1, image.data_ptr(), stream)
+    torch.cuda.synchronize(device)
+    assert same(image.cpu().numpy(), ref["accum"])
+    comm.destroy()
+    # the second half without the first is an error, not a read of an unallocated buffer
+    fresh = rccl.Communicator(rccl.unique_id(), 1, 0, device_id=0)
+    with pytest.raises(RuntimeError, match="nothing was packed"):
+        fresh.gather_packed(t, 4, 0, image.data_ptr(), stream)
+    with pytest.raises(RuntimeError, match="no accumulator was staged"):
+        fresh.reduce_staged(t, 0, stream)
+    fresh.destroy()
+    t.destroy()
+
+
+@pytest.mark.parametrize("w,h,stripe_rows,world", [(160, 100, 4, 2), (96, 70, 8, 3), (64, 61, 4, 8), (50, 20, 16, 5), (33, 17, 1, 8),
+                                                   (1920, 1080, 4, 8)])
+def test_native_pack_and_unpack_kernels_for_several_ranks(pkg, w, h, stripe_rows, world):
+    """The pack and unpack kernels of librt_mi355x_rccl.so with the layout of `world` ranks, on one GPU: every
+    rank's stripes are rendered and packed into that rank's place of the buffer an all-gather would fill, and the
+    unpacked image is the unsharded one bit for bit -- ragged last stripes and ranks without a stripe in the last
+    round included."""
+    import torch
+    from raytracing_amd import rccl
+    device = torch.device("cuda", 0)
+    whole = make_tracer(pkg, w, h, 2, 6)
+    whole.render_frames(0, 2)
+    want = whole.read_accum()
+    whole.destroy()
+    per_rank = rccl.stripes_packed_bytes(w, h, stripe_rows, world)
+    stripes = (h + stripe_rows - 1) // stripe_rows
+    assert per_rank == ((stripes + world - 1) // world) * min(stripe_rows, h) * w * 16
+    gathered = torch.full((world * per_rank // 4,), float("nan"), dtype=torch.float32, device=device)
+    t = make_tracer(pkg, w, h, 2, 6)
+    for rank in range(world):
+        t.reset_accumulation()
+        t.render_stripes(0, 2, 1, stripe_rows, rank, world, write_output=False)
+        rccl.pack_stripes_to(t, stripe_rows, world, rank, gathered.data_ptr() + rank * per_rank)
+    image = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device=device)
+    rccl.unpack_stripes_from(t, stripe_rows, world, gathered.data_ptr(), image.data_ptr())
+    torch.cuda.synchronize(device)
+    assert same(image.cpu().numpy(), want)
+    assert not torch.isnan(gathered).any()          # the padding of the packed buffers is written too (zeros)
+    t.destroy()
+
+
 def _worker(rank, world, port, mode, result_path):
     sys.path.insert(0, ROOT)
     import torch

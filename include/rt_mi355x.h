@@ -113,10 +113,11 @@ int rt_get_spheres(rt_handle h, rt_gpu_sphere *out, uint32_t cap, uint32_t *n);
  * kept (smallest root, the higher index on an exact tie), so images are
  * bit-identical to testing every sphere.  The reference has no counterpart (its
  * loop visits all spheres).  enable = 0 goes back to that loop; the default is 1.
- * A hierarchy that fits the GPU's on-chip memory (scenes of up to about 7000
- * spheres) is walked as a complete four-way tree, four balls per step
- * (rt_get_scene_quadtree); enable = 2 walks the depth-first tree below, one node
- * per step, for those scenes too (same images; for comparisons).
+ * A hierarchy that fits the GPU's on-chip memory (scenes of up to about 6000
+ * spheres) is walked as a complete four-way tree of bounding boxes, four
+ * children per step (rt_get_scene_quadtree); enable = 2 walks the depth-first
+ * tree of balls below, one node per step, for those scenes too (same images; for
+ * comparisons).
  * Does not raise the reset flag. */
 int rt_set_scene_hierarchy(rt_handle h, int enable);
 /* Copies out up to cap nodes of the hierarchy of the current scene, in
@@ -138,18 +139,23 @@ int rt_get_scene_hierarchy_links(rt_handle h, float *geom, uint32_t *link, uint3
 /* The hierarchy of the current scene as the complete four-way tree that is
  * walked when it fits on chip.  The tree has *levels levels; level 0 has *roots
  * groups, every level below four times as many; the children of group g are the
- * groups 4 g + *roots + k, k = 0..3.  geom receives 16 floats per group: four
- * balls (centre, w).  In groups before *first_leaf they are the bounding balls of
- * the child groups (w = 1.125 R^2, as above), from *first_leaf on they are
- * spheres (w = radius^2) and slot_sphere[4 (g - *first_leaf) + k] is the index of
- * the sphere in ball k of group g.  An unused ball has w = -infinity and the
- * slot 0xFFFFFFFF.  The last group (index *n_groups - 1, behind the tree) holds
- * up to four spheres that are far larger than the rest and are tested for every
- * ray; *has_prologue says whether it holds any.  *n_groups = 0: the scene has no
- * such tree.  No counterpart in the reference.  Any pointer may be NULL. */
-int rt_get_scene_quadtree(rt_handle h, float *geom, uint32_t *slot_sphere, uint32_t group_cap, uint32_t slot_cap,
-                          uint32_t *n_groups, uint32_t *n_slots, uint32_t *levels, uint32_t *roots,
-                          uint32_t *first_leaf, int *has_prologue);
+ * groups 4 g + *roots + k, k = 0..3.  Groups before *first_leaf hold the
+ * axis-aligned bounding boxes of their four child groups: box receives 24 floats
+ * per such group, lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4] (an unused
+ * child: 3e38 everywhere).  Groups from *first_leaf on hold four spheres each:
+ * geom receives 16 floats per such group, (centre, radius^2) four times, and
+ * slot_sphere[4 (g - *first_leaf) + k] is the index of the sphere in slot k of
+ * group g; an unused slot has radius^2 = -infinity and the index 0xFFFFFFFF.  The
+ * last group (index *n_groups - 1, behind the tree) holds the *prologue_spheres
+ * (0..4) spheres that are far larger than the rest and are tested for every ray.
+ * bound receives five floats: centre and radius of a ball around all spheres of
+ * the tree, and their smallest radius (the walk's per-ray box margin is derived
+ * from them).  *n_groups = 0: the scene has no such tree.  No counterpart in the
+ * reference.  Any pointer may be NULL. */
+int rt_get_scene_quadtree(rt_handle h, float *box, float *geom, uint32_t *slot_sphere, uint32_t box_cap,
+                          uint32_t group_cap, uint32_t slot_cap, uint32_t *n_groups, uint32_t *n_slots,
+                          uint32_t *levels, uint32_t *roots, uint32_t *first_leaf, uint32_t *prologue_spheres,
+                          float *bound);
 
 /* RayTracer::makeCameraParams + updateParams, src/rt/RayTracer.cpp:140-177,
  * :550-557: the 160-byte block a dispatch for frame_index would receive. */

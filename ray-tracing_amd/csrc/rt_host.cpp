@@ -55,9 +55,9 @@ struct rt_tracer {
     rt::QuadTree quad;                // the same as a complete four-way tree, when that fits LDS (else empty)
     bool use_tree = true;
     bool use_quad = true;             // walk the four-way tree where there is one
-    float4* d_quad_geom = nullptr;    // four float4 per group
+    float4* d_quad_geom = nullptr;    // the four-way tree as the kernel stages it: six float4 per box group, then four per group of spheres
     rt_gpu_sphere* d_slot_spheres = nullptr; // the sphere list in slot order of the four-way tree
-    uint32_t d_quad_capacity = 0;     // groups
+    uint32_t d_quad_capacity = 0;     // bytes
     uint32_t d_slot_capacity = 0;     // slots
     bool scene_bounded = false;       // every sphere finite, |centre| and |radius| at most 2^20
     float4* d_tree_geom = nullptr;
@@ -472,8 +472,12 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
     // fourth albedo component (all ones for an unused slot)
     const uint32_t quad_groups = index.quad.group_count();
     const uint32_t quad_slots = index.quad.slot_count();
+    const uint32_t quad_bytes = static_cast<uint32_t>(index.quad.lds_bytes());
     std::vector<rt_gpu_sphere> slot_spheres;
+    std::vector<float> quad_image; // box groups, then the groups of spheres
     if (quad_groups != 0) {
+        quad_image = index.quad.box;
+        quad_image.insert(quad_image.end(), index.quad.geom.begin(), index.quad.geom.end());
         slot_spheres.assign(quad_slots, rt_gpu_sphere{});
         for (uint32_t slot = 0; slot < quad_slots; ++slot) {
             const uint32_t sphere = index.quad.slot_sphere[slot];
@@ -510,7 +514,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
             RT_HIP_TRY(h, d_loop_geom.take(h->d_loop_geom, h->d_loop_geom_capacity, n, static_cast<size_t>(n) * sizeof(float4)));
         }
         if (quad_groups != 0) {
-            RT_HIP_TRY(h, d_quad_geom.take(h->d_quad_geom, h->d_quad_capacity, quad_groups, static_cast<size_t>(quad_groups) * 4u * sizeof(float4)));
+            RT_HIP_TRY(h, d_quad_geom.take(h->d_quad_geom, h->d_quad_capacity, quad_bytes, quad_bytes));
             RT_HIP_TRY(h, d_slot_spheres.take(h->d_slot_spheres, h->d_slot_capacity, quad_slots, static_cast<size_t>(quad_slots) * sizeof(rt_gpu_sphere)));
         }
         return RT_OK;
@@ -529,7 +533,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
                 RT_HIP_TRY(h, hipMemcpy(d_loop_geom.ptr, loop_geom.data(), loop_geom.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             if (quad_groups != 0) {
-                RT_HIP_TRY(h, hipMemcpy(d_quad_geom.ptr, index.quad.geom.data(), index.quad.geom.size() * sizeof(float), hipMemcpyHostToDevice));
+                RT_HIP_TRY(h, hipMemcpy(d_quad_geom.ptr, quad_image.data(), quad_image.size() * sizeof(float), hipMemcpyHostToDevice));
                 RT_HIP_TRY(h, hipMemcpy(d_slot_spheres.ptr, slot_spheres.data(), slot_spheres.size() * sizeof(rt_gpu_sphere), hipMemcpyHostToDevice));
             }
             return RT_OK;
@@ -577,7 +581,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
     if (d_quad_geom.fresh) {
         if (h->d_quad_geom) { (void)hipFree(h->d_quad_geom); }
         h->d_quad_geom = static_cast<float4*>(d_quad_geom.ptr);
-        h->d_quad_capacity = quad_groups;
+        h->d_quad_capacity = quad_bytes;
     }
     if (d_slot_spheres.fresh) {
         if (h->d_slot_spheres) { (void)hipFree(h->d_slot_spheres); }
@@ -842,6 +846,8 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.tree_nodes = tree ? h->tree.node_count() : 0u;
         args.tree_packed = tree && h->tree.packed() ? rt::kTreeFormatPacked : rt::kTreeFormatGlobal;
         args.quad_roots = args.quad_first_leaf = args.quad_prologue = 0u;
+        args.quad_margin = 0.0f;
+        args.quad_bound = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (quad) {
             args.tree_geom = h->d_quad_geom;
             args.tree_word = nullptr;
@@ -849,7 +855,9 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             args.tree_packed = rt::kTreeFormatQuad;
             args.quad_roots = h->quad.roots;
             args.quad_first_leaf = h->quad.first_leaf;
-            args.quad_prologue = h->quad.has_prologue ? 1u : 0u;
+            args.quad_prologue = h->quad.prologue_spheres;
+            args.quad_bound = make_float4(h->quad.bound_centre[0], h->quad.bound_centre[1], h->quad.bound_centre[2], h->quad.bound_radius);
+            args.quad_margin = 26.0f * 0x1p-24f / h->quad.min_radius;
             args.spheres = h->d_slot_spheres; // `best` of that walk is a slot
         }
         args.loop_geom = h->d_loop_geom;
@@ -1323,9 +1331,9 @@ int rt_get_scene_hierarchy_links(rt_handle h, float* geom, uint32_t* link, uint3
     return RT_OK;
 }
 
-int rt_get_scene_quadtree(rt_handle h, float* geom, uint32_t* slot_sphere, uint32_t group_cap, uint32_t slot_cap,
-                          uint32_t* n_groups, uint32_t* n_slots, uint32_t* levels, uint32_t* roots, uint32_t* first_leaf,
-                          int* has_prologue)
+int rt_get_scene_quadtree(rt_handle h, float* box, float* geom, uint32_t* slot_sphere, uint32_t box_cap, uint32_t group_cap,
+                          uint32_t slot_cap, uint32_t* n_groups, uint32_t* n_slots, uint32_t* levels, uint32_t* roots,
+                          uint32_t* first_leaf, uint32_t* prologue_spheres, float* bound)
 {
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
@@ -1336,8 +1344,17 @@ int rt_get_scene_quadtree(rt_handle h, float* geom, uint32_t* slot_sphere, uint3
     if (levels) { *levels = q.levels; }
     if (roots) { *roots = q.roots; }
     if (first_leaf) { *first_leaf = q.first_leaf; }
-    if (has_prologue) { *has_prologue = q.has_prologue ? 1 : 0; }
-    const uint32_t groups = std::min(group_cap, q.group_count());
+    if (prologue_spheres) { *prologue_spheres = q.prologue_spheres; }
+    if (bound != nullptr) {
+        std::memcpy(bound, q.bound_centre, sizeof q.bound_centre);
+        bound[3] = q.bound_radius;
+        bound[4] = q.min_radius;
+    }
+    const uint32_t boxes = std::min(box_cap, q.first_leaf);
+    if (box != nullptr && boxes != 0 && !q.empty()) {
+        std::memcpy(box, q.box.data(), sizeof(float) * 24u * boxes);
+    }
+    const uint32_t groups = std::min(group_cap, static_cast<uint32_t>(q.geom.size() / 16u));
     if (geom != nullptr && groups != 0) {
         std::memcpy(geom, q.geom.data(), sizeof(float) * 16u * groups);
     }

@@ -160,7 +160,7 @@ enum SceneMode {
     kTree = 2,    // hierarchy nodes in LDS, sphere records read from memory for the winner
     kTreeGlobal = 3, // hierarchy too large for LDS (or for the packed node word): walked in global memory
     kGeomGlobal = 4, // no hierarchy and too many spheres for LDS: geometry records read from global memory
-    kTreeQuad = 6,   // the complete four-way tree (rt_tree.hpp: QuadTree) in LDS, four balls per trip of the walk
+    kTreeQuad = 6,   // the complete four-way tree of boxes (rt_tree.hpp: QuadTree) in LDS, four children per trip of the walk
     kFullLds5 = 5    // kFullLds for exactly five spheres (the reference's own scene, src/rt/RayTracer.cpp:105-138):
                      // the sphere loop is unrolled and every LDS offset is a constant
 };
@@ -201,11 +201,11 @@ __device__ __forceinline__ void stage_tree(const float4* __restrict__ node_geom,
     __syncthreads();
 }
 
-// Copies the groups of the four-way tree into LDS (four float4 per group).
-__device__ __forceinline__ void stage_quad_tree(const float4* __restrict__ group_geom, uint32_t groups, float4* geom)
+// Copies the four-way tree into LDS: six float4 per box group, then four per group of spheres.
+__device__ __forceinline__ void stage_quad_tree(const float4* __restrict__ tree, uint32_t records, float4* lds_tree)
 {
-    for (uint32_t i = threadIdx.x; i < 4u * groups; i += blockDim.x) {
-        geom[i] = group_geom[i];
+    for (uint32_t i = threadIdx.x; i < records; i += blockDim.x) {
+        lds_tree[i] = tree[i];
     }
     __syncthreads();
 }
@@ -221,6 +221,19 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool predicate)
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// The kernel's argument struct as it lies in the kernel-argument segment (it is the only argument).
+// Blocks that run rarely read what they need from there instead of keeping it in scalar registers
+// through the whole trace loop, which is short of them; the empty asm keeps the compiler from
+// recognising the copy.  The pointer stays in the constant address space, so that the reads are scalar
+// loads (through a generic pointer they would be per-lane flat loads).
+typedef const __attribute__((address_space(4))) TraceArgs* KernelArgs;
+__device__ __forceinline__ KernelArgs args_in_memory()
+{
+    auto segment = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(segment));
+    return (KernelArgs)segment;
 }
 
 // Closest hit of one ray segment over the whole scene, raytrace.comp.glsl:244-259: `closest` and
@@ -307,11 +320,13 @@ struct TreeWalk {
     float4 g;            // the node at `at`, fetched ahead
     uint32_t w;
     uint32_t link;       // byte offset of the node to continue at when this node's test fails
-    // the four-way tree instead of `at`, `g`, `w`, `link`:
+    // the four-way tree instead of `at`, `g`, `w`, `link`, `beyond_limit`:
     uint32_t grp;        // this lane's group; kQuadIdle: no walk in progress
     uint32_t stack;      // four bits per level above `grp`: the siblings on that level that passed their parent's
                          // test and have not been visited yet (lowest four bits: the siblings of `grp` itself)
-    uint32_t root;       // the level-0 group the walk is below (0xFFFFFFFF while it is in the prologue)
+    uint32_t root;       // the level-0 group the walk is below
+    f3 inv;              // 1 / d per axis, clamped to +-2^90
+    f3 lo_off, hi_off;   // -(o + m) * inv and -(o - m) * inv, m the margin of this ray's boxes (rt_tree.cpp)
 };
 constexpr uint32_t kQuadIdle = 0xFFFFFFFFu;
 
@@ -455,27 +470,61 @@ __device__ __forceinline__ void sphere_closest_slot(const SphereQuadratic& q, co
     }
 }
 
-// Walk of the complete four-way tree (rt_tree.hpp: QuadTree), resumable like tree_walk.  One trip = one group:
-// its four balls are fetched together and tested independently.  In a group of the last level (and in the
-// prologue) they are spheres, and those that pass go through the root arithmetic one after the other; in a group
-// above, the children whose ball passes are visited one after the other, the not yet visited ones waiting as four
-// bits of `stack`.  The tree is implicit (child k of group g is 4 g + roots + k), so going down, across and up
-// is arithmetic on the group index and needs no memory access.  `best` is a slot of the sphere list in slot order.
+// One child of a box group against the ray: whether the parameter interval inside the box, grown by the ray's
+// margin, reaches into [0, closest].  lo/hi are the child's bounds on the three axes; the arithmetic and why
+// its rounding is harmless are described in rt_tree.cpp.
+__device__ __forceinline__ bool box_reached(float lx, float ly, float lz, float hx, float hy, float hz, const TreeWalk& t)
+{
+    const float ax = __builtin_fmaf(lx, t.inv.x, t.lo_off.x), bx = __builtin_fmaf(hx, t.inv.x, t.hi_off.x);
+    const float ay = __builtin_fmaf(ly, t.inv.y, t.lo_off.y), by = __builtin_fmaf(hy, t.inv.y, t.hi_off.y);
+    const float az = __builtin_fmaf(lz, t.inv.z, t.lo_off.z), bz = __builtin_fmaf(hz, t.inv.z, t.hi_off.z);
+    const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
+    const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), t.closest);
+    return tn <= tf;
+}
+
+// Walk of the complete four-way tree (rt_tree.hpp: QuadTree), resumable like tree_walk.  One trip = one group
+// of boxes and, for a lane that comes down to the last level in that trip, the group of four spheres there as
+// well.  The children of a box group whose box the ray reaches are visited one after the other, the not yet
+// visited ones waiting as four bits of `stack`; the spheres of a last-level group are fetched together and those
+// whose discriminant allows a hit go through the root arithmetic one after the other.  The tree is implicit
+// (child k of group g is 4 g + roots + k), so going down, across and up is arithmetic on the group index and needs
+// no memory access.  `best` is a slot of the sphere list in slot order.
+// tree = the box groups (six float4 each), then the groups of spheres (four float4 each), the prologue last.
 template <class Stats>
-__device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* groups, bool live, f3 ro, f3 rd, TreeWalk& t, Stats& st)
+__device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree, bool live, f3 ro, f3 rd, TreeWalk& t, Stats& st)
 {
     const uint32_t roots = A.quad_roots, first_leaf = A.quad_first_leaf;
+    const float4* sphere_groups = tree + 2u * first_leaf; // group g of the last level starts at sphere_groups + 4 g
     if (live && t.grp == kQuadIdle) {
         // a new segment
         t.closest = 1e20f;
         t.best = -1;
-        t.beyond_limit = __builtin_inff();
         t.rden = ray_denominator(ro, rd, true); // a scene with a hierarchy is bounded
-        // the skip tests of the hierarchy are proven for rays in the bounded range only
+        // the box tests of the hierarchy are proven for rays in the bounded range only
         if (t.rden.bounded) {
+            // the spheres kept out of the tree first: a hit there bounds the walk from its first group
+            const float4* prologue = sphere_groups + 4u * (A.tree_nodes - 1u);
+            for (uint32_t k = 0; k < A.quad_prologue; ++k) {
+                const SphereQuadratic q = sphere_quadratic(prologue[k], ro, rd, t.rden.a);
+                if (!(q.discriminant < 0.0f) && !behind_origin(q.half_b, q.c)) {
+                    sphere_closest_slot(q, t.rden, kTMin, (int)(4u * (A.tree_nodes - 1u - first_leaf) + k), A.spheres, t.closest, t.best, st);
+                }
+            }
+            // this ray's box margin and slab constants (rt_tree.cpp)
+            const KernelArgs M = args_in_memory();
+            const f3 from_centre = ro - mk(M->quad_bound.x, M->quad_bound.y, M->quad_bound.z);
+            const float reach = __builtin_fmaf(__builtin_amdgcn_sqrtf(dot(from_centre, from_centre)), 1.0001f, M->quad_bound.w);
+            const float margin = __builtin_fmaf(reach, fminf(0.003f, __builtin_fmaf(reach, M->quad_margin, 2e-6f)),
+                                                3e-7f * fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)));
+            t.inv = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.x), -0x1p90f, 0x1p90f),
+                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.y), -0x1p90f, 0x1p90f),
+                       __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.z), -0x1p90f, 0x1p90f));
+            t.lo_off = mk(-(ro.x + margin) * t.inv.x, -(ro.y + margin) * t.inv.y, -(ro.z + margin) * t.inv.z);
+            t.hi_off = mk(-(ro.x - margin) * t.inv.x, -(ro.y - margin) * t.inv.y, -(ro.z - margin) * t.inv.z);
             t.stack = 0u;
-            t.root = A.quad_prologue != 0u ? 0xFFFFFFFFu : 0u;
-            t.grp = A.quad_prologue != 0u ? A.tree_nodes - 1u : 0u;
+            t.root = 0u;
+            t.grp = 0u;
         } else {
             RT_COLD_PATH();
             const uint32_t slots = 4u * (A.tree_nodes - first_leaf);
@@ -499,40 +548,50 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* grou
         return;
     }
     do {
-        if (t.grp != kQuadIdle) {
+        bool done_here = false; // nothing (more) to do below this lane's group: on to a waiting sibling or the next root
+        if (t.grp < first_leaf) {
+            // (an idle lane's group is 0xFFFFFFFF)
             st.section(ST_NODE);
-            const float4* g = groups + 4u * t.grp;
-            const float4 b0 = g[0], b1 = g[1], b2 = g[2], b3 = g[3];
-            const bool leaf = t.grp >= first_leaf;
-            // dot(oc,oc) is scaled by 1 - 2^-13 for a bounding ball and by exactly 1 for a sphere
-            const float k = leaf ? 1.0f : __uint_as_float(0x3F7FF800u);
-            const SphereQuadratic q0 = sphere_quadratic_scaled(b0, ro, rd, t.rden.a, k);
-            const SphereQuadratic q1 = sphere_quadratic_scaled(b1, ro, rd, t.rden.a, k);
-            const SphereQuadratic q2 = sphere_quadratic_scaled(b2, ro, rd, t.rden.a, k);
-            const SphereQuadratic q3 = sphere_quadratic_scaled(b3, ro, rd, t.rden.a, k);
-            // the three reasons to leave a ball out, as in tree_walk
-            const bool s0 = q0.discriminant < 0.0f || behind_origin(q0.half_b, q0.c) || q0.c - b0.w > t.beyond_limit;
-            const bool s1 = q1.discriminant < 0.0f || behind_origin(q1.half_b, q1.c) || q1.c - b1.w > t.beyond_limit;
-            const bool s2 = q2.discriminant < 0.0f || behind_origin(q2.half_b, q2.c) || q2.c - b2.w > t.beyond_limit;
-            const bool s3 = q3.discriminant < 0.0f || behind_origin(q3.half_b, q3.c) || q3.c - b3.w > t.beyond_limit;
-            const uint32_t pass = (s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u);
-            if (leaf) {
-                const int slot0 = (int)(4u * (t.grp - first_leaf));
-                for (uint32_t m = pass; m != 0u; m &= m - 1u) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(m);
-                    SphereQuadratic q = q0;
-                    if (i == 1u) { q = q1; }
-                    if (i == 2u) { q = q2; }
-                    if (i == 3u) { q = q3; }
-                    sphere_closest_slot(q, t.rden, kTMin, slot0 + (int)i, A.spheres, t.closest, t.best, st);
-                    t.beyond_limit = 2.5f * t.rden.a * t.closest * t.closest;
-                }
-            }
-            if (!leaf && pass != 0u) {
+            const float4* b = tree + 6u * t.grp;
+            const float4 lx = b[0], ly = b[1], lz = b[2], hx = b[3], hy = b[4], hz = b[5];
+            const uint32_t pass = (box_reached(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t) ? 1u : 0u) |
+                                  (box_reached(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t) ? 2u : 0u) |
+                                  (box_reached(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t) ? 4u : 0u) |
+                                  (box_reached(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t) ? 8u : 0u);
+            if (pass != 0u) {
                 // down to the first child that passed; the others wait
                 t.stack = (t.stack << 4) | (pass & (pass - 1u));
                 t.grp = 4u * t.grp + roots + (uint32_t)__builtin_ctz(pass);
-            } else if (t.stack == 0u) {
+            } else {
+                done_here = true;
+            }
+        }
+        if (!done_here && t.grp != kQuadIdle && t.grp >= first_leaf) {
+            st.section(ST_SPHERE_TEST);
+            const float4* g = sphere_groups + 4u * t.grp;
+            const float4 b0 = g[0], b1 = g[1], b2 = g[2], b3 = g[3];
+            const SphereQuadratic q0 = sphere_quadratic(b0, ro, rd, t.rden.a);
+            const SphereQuadratic q1 = sphere_quadratic(b1, ro, rd, t.rden.a);
+            const SphereQuadratic q2 = sphere_quadratic(b2, ro, rd, t.rden.a);
+            const SphereQuadratic q3 = sphere_quadratic(b3, ro, rd, t.rden.a);
+            const bool s0 = q0.discriminant < 0.0f || behind_origin(q0.half_b, q0.c);
+            const bool s1 = q1.discriminant < 0.0f || behind_origin(q1.half_b, q1.c);
+            const bool s2 = q2.discriminant < 0.0f || behind_origin(q2.half_b, q2.c);
+            const bool s3 = q3.discriminant < 0.0f || behind_origin(q3.half_b, q3.c);
+            const uint32_t pass = (s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u);
+            const int slot0 = (int)(4u * (t.grp - first_leaf));
+            for (uint32_t m = pass; m != 0u; m &= m - 1u) {
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                SphereQuadratic q = q0;
+                if (i == 1u) { q = q1; }
+                if (i == 2u) { q = q2; }
+                if (i == 3u) { q = q3; }
+                sphere_closest_slot(q, t.rden, kTMin, slot0 + (int)i, A.spheres, t.closest, t.best, st);
+            }
+            done_here = true;
+        }
+        if (done_here) {
+            if (t.stack == 0u) {
                 // nothing waits below this root: on to the next one
                 t.root += 1u;
                 t.grp = t.root < roots ? t.root : kQuadIdle;
@@ -564,19 +623,6 @@ struct Unit {
 };
 constexpr uint32_t kUnitWords = 96; // offset of the unit description in a wave's table
 constexpr uint32_t kWaveTableWords = 104;
-
-// The kernel's argument struct as it lies in the kernel-argument segment (it is the only argument).
-// Blocks that run rarely read what they need from there instead of keeping it in scalar registers
-// through the whole trace loop, which is short of them; the empty asm keeps the compiler from
-// recognising the copy.  The pointer stays in the constant address space, so that the reads are scalar
-// loads (through a generic pointer they would be per-lane flat loads).
-typedef const __attribute__((address_space(4))) TraceArgs* KernelArgs;
-__device__ __forceinline__ KernelArgs args_in_memory()
-{
-    auto segment = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(segment));
-    return (KernelArgs)segment;
-}
 
 // The next unit of the launch for this wave, from the counter the host zeroes before the launch.
 // Every lane of the wave has to be active.
@@ -657,7 +703,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     // (a float4 and a word per node)
     constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal || MODE == kTreeQuad;
     constexpr bool IN_GLOBAL = MODE == kTreeGlobal || MODE == kGeomGlobal; // nothing but the hash tables in LDS
-    const uint32_t lds_records = IN_GLOBAL ? 0u : (MODE == kTree ? A.tree_nodes : (MODE == kTreeQuad ? 4u * A.tree_nodes : sphere_count));
+    const uint32_t lds_records = IN_GLOBAL ? 0u : (MODE == kTree ? A.tree_nodes : (MODE == kTreeQuad ? 4u * A.tree_nodes + 2u * A.quad_first_leaf : sphere_count));
     float4* lds_geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
@@ -694,7 +740,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     if (MODE == kTree) {
         stage_tree(A.tree_geom, A.tree_word, A.tree_nodes, lds_geom, lds_word);
     } else if (MODE == kTreeQuad) {
-        stage_quad_tree(A.tree_geom, A.tree_nodes, lds_geom);
+        stage_quad_tree(A.tree_geom, lds_records, lds_geom);
     } else if (!IN_GLOBAL) {
         stage_scene<MAT_IN_LDS>(A.spheres, sphere_count, lds_geom, mat0, mat1, hit_rec);
     }
@@ -794,6 +840,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     walk.grp = kQuadIdle;
     walk.stack = 0u;
     walk.root = 0u;
+    walk.inv = walk.lo_off = walk.hi_off = mk(0.0f, 0.0f, 0.0f);
 
     for (;;) {
         st.section(ST_ITER);
@@ -1474,12 +1521,12 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
     }
     if (args.tree_nodes != 0) {
         if (args.tree_packed == kTreeFormatQuad) {
-            if (args.tree_geom == nullptr || args.tree_nodes > kQuadMaxGroups || args.quad_roots == 0u || args.quad_roots > kQuadMaxRoots ||
-                args.quad_first_leaf >= args.tree_nodes) {
+            // 96 bytes per box group, 64 per group of spheres; the block size follows the footprint as below
+            const size_t groups_bytes = (size_t)args.quad_first_leaf * 96u + ((size_t)args.tree_nodes - args.quad_first_leaf) * 64u;
+            if (args.tree_geom == nullptr || args.quad_first_leaf >= args.tree_nodes || groups_bytes > kQuadMaxLdsBytes ||
+                args.quad_roots == 0u || args.quad_roots > kQuadMaxRoots || args.quad_prologue > 4u) {
                 return hipErrorInvalidValue;
             }
-            // 64 bytes per group; the block size follows the footprint as below
-            const size_t groups_bytes = (size_t)args.tree_nodes * 64u;
             if (groups_bytes <= 30u * 1024u) {
                 launch_trace_as<kTreeQuad, 256, kByCounter>(args, units, groups_bytes + 4u * kWaveTableWords * 4u, stream);
             } else if (groups_bytes <= 72u * 1024u) {

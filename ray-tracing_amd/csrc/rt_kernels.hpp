@@ -39,13 +39,16 @@ struct TraceArgs {
     uint32_t tree_nodes;          // 0 = test every sphere; nodes of the depth-first tree, or groups of the four-way tree
     uint32_t tree_packed;         // kTreeFormat*: 1 = the depth-first tree fits LDS and the packed word; 0 = it is walked in
                                   // global memory, and both node arrays hold one more (unused) entry than tree_nodes;
-                                  // 2 = the complete four-way tree (rt_tree.hpp: QuadTree) in LDS: tree_geom holds four
-                                  // float4 per group, tree_word is unused, and `spheres` is the copy of the sphere list in
-                                  // slot order (one record per slot of the last level and the prologue, the sphere's
-                                  // index in the bits of albedo[3], 0xFFFFFFFF for an unused slot)
+                                  // 2 = the complete four-way tree (rt_tree.hpp: QuadTree) in LDS: tree_geom holds six
+                                  // float4 per box group, then four per group of spheres, tree_word is unused, and
+                                  // `spheres` is the copy of the sphere list in slot order (one record per slot of the
+                                  // last level and the prologue, the sphere's index in the bits of albedo[3],
+                                  // 0xFFFFFFFF for an unused slot)
     uint32_t quad_roots;          // four-way tree: groups on level 0,
-    uint32_t quad_first_leaf;     // index of the first group of the last level,
-    uint32_t quad_prologue;       // and whether the group behind the tree (index tree_nodes - 1) holds spheres
+    uint32_t quad_first_leaf;     // index of the first group of the last level (= number of box groups),
+    uint32_t quad_prologue;       // spheres in the group behind the tree (index tree_nodes - 1), 0..4,
+    float quad_margin;            // 26 * 2^-24 / smallest radius in the tree,
+    float4 quad_bound;            // and a ball (centre, radius) around the spheres of the tree
     uint32_t scene_bounded;       // every sphere finite with |centre| <= 2^20 and |radius| <= 2^20
     uint32_t width;
     uint32_t height;

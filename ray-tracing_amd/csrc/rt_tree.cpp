@@ -191,8 +191,35 @@ bool collect_items(const rt_gpu_sphere* spheres, uint32_t count, std::vector<Ite
 }
 
 // Builder of the complete four-way tree (rt_tree.hpp).
+//
+// Why the walk's box test never leaves out a sphere that the loop over all spheres would have accepted (same
+// ranges as above; u = 2^-24):
+//
+//  * Let t be a root that hitSphere computes and accepts for sphere i (centre c, radius r, oc = o - c,
+//    L = max(|oc|, r)), and P = o + t d.  With x = a t, the quantity a (|P - c|^2 - r^2) equals
+//    (x + hb)^2 - (hb^2 - a (|oc|^2 - r^2)); the computed numerator gives x + hb = -e1 -/+ s with |e1| <= 4u |oc| |d|
+//    (rounding of oc and of the dot product) and s the computed square root of the computed discriminant, which
+//    differs from the exact one by less than 32u a L^2 (first item of the list above) and is at most |d| L (1 + 2u).
+//    Hence | |P - c|^2 - r^2 | <= (8 + 2 + 32) u L^2 <= 48u L^2 after the rounding of the division, i.e.
+//    |P - c| <= sqrt(r^2 + 48u L^2): every accepted root is the parameter of a point within
+//    e_i = sqrt(r^2 + 48u L^2) - r <= min(0.0017 L, 24u L^2 / r) of the sphere's surface, and so inside the sphere's
+//    bounding box grown by e_i on every side.
+//  * The walk grows every box by one margin per ray, m = D min(0.003, 26u D / r_min + 2e-6) + 3e-7 max|o_k|, where
+//    D >= |o - C| + R for a ball (C, R) around all spheres of the tree, so D >= L for every one of them, and
+//    r_min is their smallest radius.  m exceeds every e_i by at least 2e-6 D + 3e-7 max|o_k| (or 0.0013 D).
+//  * The slab test computes, per axis, t1 = fma(lo, inv, -fl((o + m) inv)) and t2 = fma(hi, inv, -fl((o - m) inv))
+//    with inv = 1/d_k to within 2^-22 (v_rcp_f32), clamped to +-2^90.  Its roundings are those of an exact slab test
+//    against planes moved by less than 3u |o_k| + 2^-21 D (the roundings of o +- m, of the products and of inv, the
+//    last one acting over at most the 2 D a point of the tree's ball can be away from o); a clamped inv stands for a
+//    direction component of 2^-90 instead of a smaller one, which moves a point by less than 2^-47 over the largest
+//    parameter an accepted root can have (2 D / |d| <= 2^42).  All of that is inside the slack of the margin, so
+//    the computed interval [tn, tf] of a box that contains sphere i contains t.
+//  * A child is left out when max(tn, 0) > min(tf, closest).  An accepted root has tmin <= t <= closest (:125-129),
+//    so with tn <= t <= tf none of the three reasons (the line misses the box, the box is behind the origin, the
+//    box is beyond the closest hit so far) can hold for a box that contains the sphere.  NaN cannot arise: every
+//    operand is finite (unused children are boxes at 3e38, beyond every ray of the range, not infinities).
 struct QuadBuilder {
-    Builder balls;   // its items and its bounding_ball()
+    Builder balls;   // its items
     QuadTree* out;
     const rt_gpu_sphere* spheres;
 
@@ -222,18 +249,44 @@ struct QuadBuilder {
         });
     }
 
-    void set_slot(uint32_t group, uint32_t k, const float g[4])
+    static float round_down(double v)
     {
-        std::copy(g, g + 4, out->geom.begin() + (static_cast<size_t>(group) * 4u + k) * 4u);
+        const float f = static_cast<float>(v);
+        return static_cast<double>(f) > v ? std::nextafterf(f, -INFINITY) : f;
+    }
+    static float round_up(double v)
+    {
+        const float f = static_cast<float>(v);
+        return static_cast<double>(f) < v ? std::nextafterf(f, INFINITY) : f;
     }
 
+    // Child k of box group `group`: the box around items[lo, hi).
+    void set_box(uint32_t group, uint32_t k, uint32_t lo, uint32_t hi)
+    {
+        const std::vector<Item>& items = balls.items;
+        double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+        for (uint32_t i = lo; i < hi; ++i) {
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], items[i].c[a] - items[i].r);
+                mx[a] = std::max(mx[a], items[i].c[a] + items[i].r);
+            }
+        }
+        float* b = out->box.data() + static_cast<size_t>(group) * 24u;
+        for (int a = 0; a < 3; ++a) {
+            b[4 * a + k] = round_down(mn[a]);
+            b[12 + 4 * a + k] = round_up(mx[a]);
+        }
+    }
+
+    // Last-level group `group` (or the prologue) takes items[lo, hi).
     void fill_leaf_group(uint32_t group, uint32_t lo, uint32_t hi)
     {
+        const uint32_t rel = group - out->first_leaf;
         for (uint32_t i = lo; i < hi; ++i) {
             const float* cr = spheres[balls.items[i].index].center_radius;
             const float g[4] = { cr[0], cr[1], cr[2], cr[3] * cr[3] }; // the product the loop over all spheres uses
-            set_slot(group, i - lo, g);
-            out->slot_sphere[4u * (group - out->first_leaf) + (i - lo)] = balls.items[i].index;
+            std::copy(g, g + 4, out->geom.begin() + (static_cast<size_t>(rel) * 4u + (i - lo)) * 4u);
+            out->slot_sphere[4u * rel + (i - lo)] = balls.items[i].index;
         }
     }
 
@@ -255,9 +308,7 @@ struct QuadBuilder {
         split_at(cut[2], hi, cut[3] - cut[2]);
         for (uint32_t k = 0; k < 4u; ++k) {
             if (cut[k + 1u] > cut[k]) {
-                float g[4];
-                balls.bounding_ball(cut[k], cut[k + 1u], g);
-                set_slot(group, k, g);
+                set_box(group, k, cut[k], cut[k + 1u]);
                 fill_group(4u * group + out->roots + k, level + 1u, cut[k], cut[k + 1u]);
             }
         }
@@ -276,6 +327,37 @@ struct QuadBuilder {
         split_at(lo, hi, m_left);
         fill_roots(first, left, lo, lo + m_left);
         fill_roots(first + left, count - left, lo + m_left, hi);
+    }
+
+    // The ball around items[lo, hi) and their smallest radius, for the walk's margin.
+    void set_bounds(uint32_t lo, uint32_t hi)
+    {
+        const std::vector<Item>& items = balls.items;
+        double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+        double r_min = 1e300;
+        for (uint32_t i = lo; i < hi; ++i) {
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], items[i].c[a] - items[i].r);
+                mx[a] = std::max(mx[a], items[i].c[a] + items[i].r);
+            }
+            r_min = std::min(r_min, items[i].r);
+        }
+        double centre[3];
+        for (int a = 0; a < 3; ++a) {
+            out->bound_centre[a] = static_cast<float>(0.5 * (mn[a] + mx[a]));
+            centre[a] = out->bound_centre[a];
+        }
+        double radius = 0.0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            double d2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double d = items[i].c[a] - centre[a];
+                d2 += d * d;
+            }
+            radius = std::max(radius, std::sqrt(d2) + items[i].r);
+        }
+        out->bound_radius = round_up(radius * (1.0 + 1e-6));
+        out->min_radius = round_down(r_min * (1.0 - 1e-6));
     }
 };
 
@@ -308,6 +390,9 @@ bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out
         ++outliers;
     }
     const uint32_t in_tree = count - outliers;
+    if (in_tree == 0) {
+        return false;
+    }
     // Shape: the fewest groups on the last level for up to kQuadMaxRoots roots; of equal ones the fewer roots.
     const uint64_t leaf_groups_needed = (static_cast<uint64_t>(in_tree) + 3u) / 4u;
     uint64_t best_leaf_groups = 0;
@@ -336,20 +421,23 @@ bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out
         first_leaf = tree_groups;
         tree_groups += per_level;
     }
-    if (tree_groups + 1u > kQuadMaxGroups) {
+    const uint64_t sphere_groups = tree_groups - first_leaf + 1u; // the last level and the prologue
+    if (first_leaf * 96u + sphere_groups * 64u > kQuadMaxLdsBytes) {
         out.clear();
         return false;
     }
     out.first_leaf = static_cast<uint32_t>(first_leaf);
-    out.has_prologue = outliers != 0;
+    out.prologue_spheres = outliers;
+    out.box.assign(first_leaf * 24u, kQuadUnusedBox);
     const float unused[4] = { 0.0f, 0.0f, 0.0f, -INFINITY };
-    out.geom.resize((tree_groups + 1u) * 16u);
+    out.geom.resize(sphere_groups * 16u);
     for (size_t slot = 0; slot < out.geom.size() / 4u; ++slot) {
         std::copy(unused, unused + 4, out.geom.begin() + slot * 4u);
     }
-    out.slot_sphere.assign((tree_groups + 1u - first_leaf) * 4u, kTreeNoSphere);
+    out.slot_sphere.assign(sphere_groups * 4u, kTreeNoSphere);
     b.fill_leaf_group(static_cast<uint32_t>(tree_groups), 0u, outliers); // the prologue sits behind the tree
     b.fill_roots(0u, out.roots, outliers, count);
+    b.set_bounds(outliers, count);
     return true;
 }
 

@@ -74,47 +74,64 @@ struct SphereTree {
     }
 };
 
-// ---- the same hierarchy as a complete four-way tree, for scenes whose tree fits LDS ------------------------
-// Groups of four balls, visited one group per trip of the walk: the four tests are independent, so their four
-// LDS reads are in flight together and a segment's chain of dependent reads is a quarter as long as with one node
-// per trip.  The tree is complete and implicit: `roots` groups on level 0, four times as many on each level
-// below, `levels` levels; group g of the tree has the children 4 g + roots + k (k = 0..3) and the parent
-// (g - roots) / 4, so no links are stored.  A group above the last level holds the inflated bounding balls of its
-// four child groups (w = 1.125 R^2 rounded up, tested with dot(oc,oc) scaled by 1 - 2^-13, as in the tree above);
-// a group of the last level holds four spheres, (centre, radius^2), tested with hitSphere's own arithmetic.  An
-// unused slot has w = -infinity, which no ray passes.  Spheres are dealt out evenly (every split is at the
+// ---- a complete four-way tree of bounding boxes, for scenes whose tree fits LDS ---------------------------
+// Groups of four children, visited one group per trip of the walk: the four tests are independent, so their LDS
+// reads are in flight together and a segment's chain of dependent reads is short.  The tree is complete and
+// implicit: `roots` groups on level 0, four times as many on each level below, `levels` levels; group g of the
+// tree has the children 4 g + roots + k (k = 0..3) and the parent (g - roots) / 4, so no links are stored.
+//
+// A group above the last level holds the axis-aligned bounding boxes of its four child groups, 24 floats laid
+// out as lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4]: the smallest box around the spheres below the
+// child, each bound rounded outward to binary32.  Boxes are far tighter than balls around spheres that lie on
+// a plane (a ray that passes ten radii above a field of small spheres misses the box of every part of it).
+// An unused child has lo = hi = 3e38 on every axis, which no ray of the bounded range reaches.
+// A group of the last level holds four spheres, (centre, radius^2), tested with hitSphere's own arithmetic;
+// an unused slot has w = -infinity, which no ray passes.  Spheres are dealt out evenly (every split is at the
 // median count, along the longest axis of the part's centres), so the depth of every sphere is the same.
-// Spheres far larger than the rest (the ground under a field of small spheres) would inflate every ball above
+// Spheres far larger than the rest (the ground under a field of small spheres) would inflate every box above
 // them; up to four of them are kept out of the tree in one more group of the last-level kind, the prologue,
-// stored behind the tree (group index group_count - 1) and visited first by every ray.
+// stored behind the tree (group index group_count - 1) and tested first for every ray.
 // slot_sphere[4 (g - first_leaf) + k] is the sphere in slot k of last-level group g (the prologue included).
+//
+// The walk inflates every box by a margin that depends on the ray (rt_tree.cpp derives it); for that it needs a
+// ball (bound_centre, bound_radius) around all spheres of the tree (the prologue's excluded) and their smallest
+// radius.
 struct QuadTree {
     uint32_t levels = 0;      // 0: no tree
     uint32_t roots = 0;       // groups on level 0, 1..kQuadMaxRoots
-    uint32_t first_leaf = 0;  // index of the first group of the last level
-    bool has_prologue = false;
-    std::vector<float> geom;           // 16 floats per group: tree groups level by level, then the prologue
+    uint32_t first_leaf = 0;  // index of the first group of the last level = number of box groups
+    uint32_t prologue_spheres = 0; // spheres in the prologue, 0..4 (they fill its first slots)
+    float bound_centre[3] = { 0.0f, 0.0f, 0.0f };
+    float bound_radius = 0.0f;
+    float min_radius = 0.0f;
+    std::vector<float> box;            // 24 floats per group above the last level
+    std::vector<float> geom;           // 16 floats per group of the last level, then the prologue
     std::vector<uint32_t> slot_sphere; // kTreeNoSphere for an unused slot
-    uint32_t group_count() const { return static_cast<uint32_t>(geom.size() / 16u); }
+    uint32_t group_count() const { return levels == 0 ? 0u : first_leaf + static_cast<uint32_t>(geom.size() / 16u); }
     uint32_t slot_count() const { return static_cast<uint32_t>(slot_sphere.size()); }
+    bool has_prologue() const { return prologue_spheres != 0; }
+    // bytes of the tree as the kernel keeps it in LDS: 96 per box group, 64 per group of spheres
+    size_t lds_bytes() const { return static_cast<size_t>(first_leaf) * 96u + (geom.size() / 16u) * 64u; }
     bool empty() const { return levels == 0; }
     void clear()
     {
-        levels = roots = first_leaf = 0;
-        has_prologue = false;
+        levels = roots = first_leaf = prologue_spheres = 0;
+        bound_radius = min_radius = 0.0f;
+        box.clear();
         geom.clear();
         slot_sphere.clear();
     }
 };
 constexpr uint32_t kQuadMaxRoots = 16;
-// Most groups a four-way tree kept in LDS may have: 64 bytes per group plus the hash tables of sixteen waves
-// within the 160 KiB of a compute unit.
-constexpr uint32_t kQuadMaxGroups = 2440;
+// Most bytes a four-way tree kept in LDS may take: with the hash tables of sixteen waves it has to fit the
+// 160 KiB of a compute unit.
+constexpr size_t kQuadMaxLdsBytes = 152u * 1024u;
 // Levels below the roots the walk's stack of pending-sibling masks (four bits per level in one register) holds.
 constexpr uint32_t kQuadMaxLevels = 9;
+constexpr float kQuadUnusedBox = 3.0e38f;
 
 // Builds the four-way tree for the scenes build_sphere_tree accepts; returns false (and leaves `out` empty) for the
-// others and for trees of more than kQuadMaxGroups groups.
+// others and for trees of more than kQuadMaxLdsBytes bytes.
 bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out);
 
 // Builds the hierarchy.  Returns false (and leaves `out` empty) when the scene does not qualify:

@@ -63,9 +63,10 @@ ABI = {
     "rt_get_scene_hierarchy": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, ctypes.POINTER(_U32)]),
     "rt_get_scene_hierarchy_links": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _U32,
                                                     ctypes.POINTER(_U32)]),
-    "rt_get_scene_quadtree": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, _U32, _U32, ctypes.POINTER(_U32),
+    "rt_get_scene_quadtree": (ctypes.c_int, [_H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _U32, _U32, _U32,
                                              ctypes.POINTER(_U32), ctypes.POINTER(_U32), ctypes.POINTER(_U32),
-                                             ctypes.POINTER(_U32), ctypes.POINTER(ctypes.c_int)]),
+                                             ctypes.POINTER(_U32), ctypes.POINTER(_U32), ctypes.POINTER(_U32),
+                                             ctypes.c_void_p]),
     "rt_set_frame_overlap": (ctypes.c_int, [_H, ctypes.c_int]),
     "rt_get_params": (ctypes.c_int, [_H, _U32, ctypes.POINTER(GPUParams)]),
     "rt_reset_accumulation": (ctypes.c_int, [_H]),
@@ -237,19 +238,26 @@ class RayTracer:
         self._check(self._lib.rt_set_scene_hierarchy(self._h, int(enable) if enable in (0, 1, 2) else (1 if enable else 0)))
 
     def get_scene_quadtree(self):
-        """The current scene's complete four-way tree: dict(geom (groups, 4, 4) float32, slot_sphere (slots,) uint32,
-        levels, roots, first_leaf, has_prologue); geom has no groups when the scene has no such tree."""
-        n_groups, n_slots, levels, roots, first_leaf = _U32(), _U32(), _U32(), _U32(), _U32()
-        prologue = ctypes.c_int()
+        """The current scene's complete four-way tree of bounding boxes: dict(box (first_leaf, 6, 4) float32 -- lo.x,
+        lo.y, lo.z, hi.x, hi.y, hi.z of the four children of a group above the last level --, geom (groups - first_leaf,
+        4, 4) float32 -- the groups of four spheres (centre, radius^2) of the last level, then the prologue --,
+        slot_sphere (slots,) uint32, groups, levels, roots, first_leaf, prologue_spheres, bound_centre, bound_radius,
+        min_radius); groups == 0 when the scene has no such tree."""
+        n_groups, n_slots, levels, roots, first_leaf, prologue = _U32(), _U32(), _U32(), _U32(), _U32(), _U32()
         refs = [ctypes.byref(v) for v in (n_groups, n_slots, levels, roots, first_leaf, prologue)]
-        self._check(self._lib.rt_get_scene_quadtree(self._h, None, None, 0, 0, *refs))
-        geom = np.zeros((n_groups.value, 4, 4), dtype=np.float32)
+        bound = np.zeros(5, dtype=np.float32)
+        self._check(self._lib.rt_get_scene_quadtree(self._h, None, None, None, 0, 0, 0, *refs, bound.ctypes.data))
+        n_box = first_leaf.value if n_groups.value else 0
+        n_geom = n_groups.value - n_box
+        box = np.zeros((n_box, 6, 4), dtype=np.float32)
+        geom = np.zeros((n_geom, 4, 4), dtype=np.float32)
         slot_sphere = np.zeros((n_slots.value,), dtype=np.uint32)
         if n_groups.value:
-            self._check(self._lib.rt_get_scene_quadtree(self._h, geom.ctypes.data, slot_sphere.ctypes.data, n_groups.value,
-                                                        n_slots.value, *refs))
-        return {"geom": geom, "slot_sphere": slot_sphere, "levels": levels.value, "roots": roots.value,
-                "first_leaf": first_leaf.value, "has_prologue": bool(prologue.value)}
+            self._check(self._lib.rt_get_scene_quadtree(self._h, box.ctypes.data, geom.ctypes.data, slot_sphere.ctypes.data,
+                                                        n_box, n_geom, n_slots.value, *refs, bound.ctypes.data))
+        return {"box": box, "geom": geom, "slot_sphere": slot_sphere, "groups": n_groups.value, "levels": levels.value,
+                "roots": roots.value, "first_leaf": first_leaf.value, "prologue_spheres": prologue.value,
+                "bound_centre": bound[:3].copy(), "bound_radius": float(bound[3]), "min_radius": float(bound[4])}
 
     def set_frame_overlap(self, enable):
         """Consecutive single-frame calls overlap on the GPU (default); False keeps every launch on the

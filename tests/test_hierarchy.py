@@ -320,22 +320,27 @@ def _quad(pkg, scene):
     return q
 
 
+UNUSED_BOX = F(3.0e38)
+
+
 def _check_quad_structure(scene, q):
-    geom, slot_sphere = q["geom"], q["slot_sphere"]
-    groups, levels, roots, first_leaf = len(geom), q["levels"], q["roots"], q["first_leaf"]
+    box, geom, slot_sphere = q["box"], q["geom"], q["slot_sphere"]
+    groups, levels, roots, first_leaf = q["groups"], q["levels"], q["roots"], q["first_leaf"]
     assert levels >= 1 and 1 <= roots <= 16
     per_level = [roots * 4 ** l for l in range(levels)]
     assert groups == sum(per_level) + 1                          # the tree, then the prologue
-    assert first_leaf == sum(per_level[:-1])
+    assert first_leaf == sum(per_level[:-1]) == len(box)
+    assert len(geom) == groups - first_leaf
     assert len(slot_sphere) == 4 * (groups - first_leaf)
+    assert 96 * first_leaf + 64 * len(geom) <= 152 * 1024           # what the kernel stages in LDS
     used = slot_sphere != NONE
     assert sorted(slot_sphere[used].tolist()) == list(range(len(scene)))     # every sphere in exactly one slot
-    leaf_geom = geom[first_leaf:].reshape(-1, 4)
+    leaf_geom = geom.reshape(-1, 4)
     s = scene[slot_sphere[used]]
     assert np.array_equal(leaf_geom[used, :3], s[:, :3])
     assert np.array_equal(leaf_geom[used, 3], s[:, 3] * s[:, 3])             # the float product the loop uses
     assert np.all(np.isneginf(leaf_geom[~used, 3]))
-    assert q["has_prologue"] == bool(used[-4:].any())
+    assert q["prologue_spheres"] == int(used[-4:].sum()) and np.all(used[-4:][:q["prologue_spheres"]])
     # spheres are dealt out evenly: the groups of the last level differ by at most one sphere
     per_group = used[:-4].reshape(-1, 4).sum(1)
     assert per_group.max() - per_group.min() <= 1 and per_group.max() >= 1
@@ -346,15 +351,15 @@ def _check_quad_structure(scene, q):
         out = []
         for k in range(4):
             below = spheres_below(4 * g + roots + k, level + 1)
-            ball = geom[g, k]
+            lo, hi = box[g, 0:3, k].astype(np.float64), box[g, 3:6, k].astype(np.float64)
             if not below:
-                assert np.isneginf(ball[3])
+                assert np.all(box[g, :, k] == UNUSED_BOX)
                 continue
-            centre = ball[:3].astype(np.float64)
-            radius = np.sqrt(float(ball[3]) / 1.125)
             c = scene[below, :3].astype(np.float64)
-            r = scene[below, 3].astype(np.float64)
-            assert np.all(np.sqrt(((c - centre) ** 2).sum(1)) + r <= radius * (1.0 + 1e-6))
+            r = np.sqrt((scene[below, 3] * scene[below, 3]).astype(np.float64))          # the radius the kernel's r^2 stands for
+            assert np.all(c - r[:, None] >= lo) and np.all(c + r[:, None] <= hi)         # contains every sphere below
+            assert np.all((c - r[:, None]).min(0) - lo <= 1e-6 * (1.0 + np.abs(lo)))     # and is tight
+            assert np.all(hi - (c + r[:, None]).max(0) <= 1e-6 * (1.0 + np.abs(hi)))
             out += below
         return out
 
@@ -362,6 +367,11 @@ def _check_quad_structure(scene, q):
     for root in range(roots):
         in_tree += spheres_below(root, 0)
     assert sorted(in_tree + [int(x) for x in slot_sphere[-4:] if x != NONE]) == list(range(len(scene)))
+    # the ball and the smallest radius the walk's margin is derived from cover the spheres of the tree
+    c = scene[in_tree, :3].astype(np.float64)
+    r = np.sqrt((scene[in_tree, 3] * scene[in_tree, 3]).astype(np.float64))
+    assert np.all(np.sqrt(((c - q["bound_centre"].astype(np.float64)) ** 2).sum(1)) + r <= q["bound_radius"])
+    assert 0.0 < q["min_radius"] <= r.min()
 
 
 @pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "synthetic24", "synthetic4097", "random", "clusters"])
@@ -370,84 +380,122 @@ def test_quadtree_structure(pkg, name):
              "synthetic24": lambda: pkg.synthetic_scene(24), "synthetic4097": lambda: pkg.synthetic_scene(4097),
              "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
     q = _quad(pkg, scene)
-    assert 0 < len(q["geom"]) <= 2440
+    assert q["groups"] > 0
     _check_quad_structure(scene, q)
     q2 = _quad(pkg, scene)
-    assert np.array_equal(q["geom"].view(np.uint32), q2["geom"].view(np.uint32)) and np.array_equal(q["slot_sphere"], q2["slot_sphere"])
+    assert all(np.array_equal(q[k].view(np.uint32), q2[k].view(np.uint32)) for k in ("box", "geom", "slot_sphere"))
     if name == "synthetic4096":
         # the ground sphere is kept out of the tree; 4095 spheres fill 1024 groups of the sixth level
-        assert q["has_prologue"] and q["slot_sphere"][-4] == 0 and q["levels"] == 6 and q["roots"] == 1
+        assert q["prologue_spheres"] == 1 and q["slot_sphere"][-4] == 0 and q["levels"] == 6 and q["roots"] == 1
 
 
 def test_scenes_without_quadtree(pkg):
     t = pkg.RayTracer().create(64, 64, device_id=-1)
-    assert len(t.get_scene_quadtree()["geom"]) == 0           # the default five spheres
+    assert t.get_scene_quadtree()["groups"] == 0           # the default five spheres
     t.set_spheres(pkg.synthetic_scene(23))
-    assert len(t.get_scene_quadtree()["geom"]) == 0
+    assert t.get_scene_quadtree()["groups"] == 0
     scene = pkg.synthetic_scene(200)
     scene[77, 0] = np.nan
     t.set_spheres(scene)
-    assert len(t.get_scene_quadtree()["geom"]) == 0
+    assert t.get_scene_quadtree()["groups"] == 0
     t.set_spheres(pkg.synthetic_scene(9000))                  # does not fit LDS: only the depth-first tree exists
-    assert len(t.get_scene_quadtree()["geom"]) == 0
+    assert t.get_scene_quadtree()["groups"] == 0
     assert len(t.get_scene_hierarchy_links()[1]) > 0
     t.destroy()
 
 
+def _fma(a, b, c):
+    """fma in binary32 for the box test (the product of two binary32 values is exact in binary64; the second
+    rounding of the sum can differ from a true fma in the last bit, far inside the margin the test is about)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def _slab_constants(q, o, d):
+    """Per ray: 1/d clamped to +-2^90 and the two offsets -(o +- m) / d of the kernel's box test, m the ray's margin."""
+    with np.errstate(divide="ignore", over="ignore"):
+        inv = np.clip(F(1.0) / d, F(-2.0 ** 90), F(2.0 ** 90)).astype(np.float32)
+    fc = o - q["bound_centre"][None, :]
+    reach = np.sqrt(_dot(fc, fc)) * F(1.0001) + F(q["bound_radius"])
+    k = F(26.0) * F(2.0 ** -24) / F(q["min_radius"])
+    margin = (reach * np.minimum(F(0.003), reach * k + F(2e-6)) + F(3e-7) * np.abs(o).max(axis=-1)).astype(np.float32)
+    lo_off = (-(o + margin[:, None]) * inv).astype(np.float32)
+    hi_off = (-(o - margin[:, None]) * inv).astype(np.float32)
+    return inv, lo_off, hi_off, margin
+
+
+def _box_interval(lo, hi, inv, lo_off, hi_off):
+    """[tn, tf] of the kernel's slab test before the clamps to 0 and `closest`; lo/hi (..., 3)."""
+    a = _fma(lo, inv, lo_off)
+    b = _fma(hi, inv, hi_off)
+    return np.minimum(a, b).max(axis=-1), np.maximum(a, b).min(axis=-1)
+
+
 def _quad_walk_closest(q, scene, o, d):
-    """The kernel's walk of the four-way tree in float32, ray by ray: four balls per visited group, pending siblings
-    as four bits per level, spheres resolved in slot order with ties going to the higher sphere index."""
-    geom, slot_sphere = q["geom"], q["slot_sphere"]
-    roots, first_leaf, groups = q["roots"], q["first_leaf"], len(q["geom"])
+    """The kernel's walk of the four-way tree in float32, ray by ray: prologue spheres first, four boxes per visited
+    group, pending siblings as four bits per level, spheres of a last-level group resolved in slot order with ties
+    going to the higher sphere index."""
+    box, geom, slot_sphere = q["box"], q["geom"], q["slot_sphere"]
+    roots, first_leaf, groups = q["roots"], q["first_leaf"], q["groups"]
     rays = o.shape[0]
     out_closest = np.full(rays, 1e20, dtype=np.float32)
     out_best = np.full(rays, -1, dtype=np.int64)
+    inv_all, lo_off_all, hi_off_all, _ = _slab_constants(q, o, d)
     visits = 0
     for ray in range(rays):
         ro, rd = o[ray], d[ray]
         a = _dot(rd, rd)
-        closest, best, limit = F(1e20), -1, F(np.inf)
-        stack = 0
-        root = -1 if q["has_prologue"] else 0
-        grp = groups - 1 if q["has_prologue"] else 0
+        inv, lo_off, hi_off = inv_all[ray], lo_off_all[ray], hi_off_all[ray]
+        state = {"closest": F(1e20), "best": -1}
+
+        def spheres(rel_group, only=4):
+            balls = geom[rel_group][:only]
+            with np.errstate(invalid="ignore", over="ignore"):
+                hb, c, disc = _quadratic(balls[:, :3], balls[:, 3], ro[None, :], rd[None, :], a, F(1.0))
+                ok = _passes(hb, c, disc)
+            for k in np.nonzero(ok)[0]:
+                with np.errstate(invalid="ignore", over="ignore"):
+                    root_t, found = _roots(hb[k:k + 1], disc[k:k + 1], a, F(0.001), state["closest"])
+                if not found[0]:
+                    continue
+                slot = 4 * rel_group + int(k)
+                if root_t[0] < state["closest"] or state["best"] < 0 or slot_sphere[slot] > slot_sphere[state["best"]]:
+                    state["closest"], state["best"] = root_t[0], slot
+
+        spheres(groups - 1 - first_leaf, q["prologue_spheres"])
+        stack, root, grp = 0, 0, 0
         while grp is not None:
             visits += 1
-            balls = geom[grp]
-            leaf = grp >= first_leaf
-            scale = F(1.0) if leaf else KEEP
-            with np.errstate(invalid="ignore", over="ignore"):
-                hb, c, disc = _quadratic(balls[:, :3], balls[:, 3], ro[None, :], rd[None, :], a, scale)
-                ok = _passes(hb, c, disc) & ~(c - balls[:, 3] > limit)
-            if leaf:
-                for k in np.nonzero(ok)[0]:
-                    with np.errstate(invalid="ignore", over="ignore"):
-                        root_t, found = _roots(hb[k:k + 1], disc[k:k + 1], a, F(0.001), closest)
-                    if not found[0]:
-                        continue
-                    slot = 4 * (grp - first_leaf) + int(k)
-                    if root_t[0] < closest or best < 0 or slot_sphere[slot] > slot_sphere[best]:
-                        closest, best = root_t[0], slot
-                    limit = F(2.5) * a * closest * closest
-                ok[:] = False
-            mask = int(sum(1 << k for k in range(4) if ok[k]))
-            if mask:
-                k = (mask & -mask).bit_length() - 1
-                stack = (stack << 4) | (mask & (mask - 1))
-                assert stack < 2 ** 32
-                grp = 4 * grp + roots + k
-            elif stack == 0:
-                root += 1
-                grp = root if root < roots else None
-            else:
-                up = ((stack & -stack).bit_length() - 1) >> 2
-                stack >>= 4 * up
-                for _ in range(up):
-                    grp = (grp - roots) >> 2
-                k = (stack & -stack).bit_length() - 1
-                stack &= stack - 1
-                grp = ((grp - roots) & ~3) + roots + k
-        out_closest[ray] = closest
-        out_best[ray] = -1 if best < 0 else int(slot_sphere[best])
+            done = False
+            if grp < first_leaf:
+                lo, hi = box[grp, 0:3, :].T, box[grp, 3:6, :].T          # (child, axis)
+                with np.errstate(invalid="ignore", over="ignore"):
+                    tn, tf = _box_interval(lo, hi, inv[None, :], lo_off[None, :], hi_off[None, :])
+                ok = np.maximum(tn, F(0.0)) <= np.minimum(tf, state["closest"])
+                mask = int(sum(1 << k for k in range(4) if ok[k]))
+                if mask:
+                    k = (mask & -mask).bit_length() - 1
+                    stack = (stack << 4) | (mask & (mask - 1))
+                    assert stack < 2 ** 32
+                    grp = 4 * grp + roots + k
+                else:
+                    done = True
+            if not done and grp >= first_leaf:
+                spheres(grp - first_leaf)
+                done = True
+            if done:
+                if stack == 0:
+                    root += 1
+                    grp = root if root < roots else None
+                else:
+                    up = ((stack & -stack).bit_length() - 1) >> 2
+                    stack >>= 4 * up
+                    for _ in range(up):
+                        grp = (grp - roots) >> 2
+                    k = (stack & -stack).bit_length() - 1
+                    stack &= stack - 1
+                    grp = ((grp - roots) & ~3) + roots + k
+        out_closest[ray] = state["closest"]
+        out_best[ray] = -1 if state["best"] < 0 else int(slot_sphere[state["best"]])
     return out_closest, out_best, visits
 
 
@@ -480,7 +528,62 @@ def test_quad_walk_finds_the_hit_of_the_loop_over_all_spheres(pkg, name):
         assert np.array_equal(closest[sl].view(np.uint32), want_closest.view(np.uint32))
         hits += int(any_hit.sum())
     assert hits > rays // 2
-    assert visits < (0.1 if len(scene) > 1000 else 0.6) * rays * len(q["geom"])       # group visits: the walk does prune
+    assert visits < (0.04 if len(scene) > 1000 else 0.6) * rays * q["groups"]       # group visits: the walk does prune
+
+
+@pytest.mark.parametrize("name", ["synthetic4096", "random", "clusters"])
+def test_accepted_roots_lie_inside_the_grown_boxes(pkg, name):
+    """What the box walk rests on: every root that the float32 evaluation of hitSphere accepts for a sphere lies
+    inside the parameter interval [tn, tf] that the kernel's slab test computes for ANY box containing the sphere
+    (checked against the sphere's own bounding box, the smallest such box), with room to spare: the interval of a
+    box grown by only a third of the ray's margin already contains it."""
+    scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "random": pkg.random_scene,
+             "clusters": lambda: _cluster_scene(pkg)}[name]()
+    q = _quad(pkg, scene)
+    in_tree = np.sort(q["slot_sphere"][:-4][q["slot_sphere"][:-4] != NONE]).astype(np.int64)
+    rays = 1500 if name == "synthetic4096" else 3000
+    o, d = _rays(scene, rays, seed=53)
+    a = _dot(d, d)
+    inv, lo_off, hi_off, margin = _slab_constants(q, o, d)
+    with np.errstate(divide="ignore", over="ignore"):
+        third = (margin * F(1.0 / 3.0))[:, None]
+        lo_off3 = (-(o + third) * inv).astype(np.float32)
+        hi_off3 = (-(o - third) * inv).astype(np.float32)
+    centre = scene[in_tree, :3]
+    radius = scene[in_tree, 3]
+    r2 = radius * radius
+    r_seen = np.sqrt(r2.astype(np.float64))[:, None]                    # the radius the kernel's r^2 stands for
+    lo_box = centre.astype(np.float64) - r_seen
+    hi_box = centre.astype(np.float64) + r_seen
+    lo_box = np.nextafter(lo_box.astype(np.float32), F(-np.inf))       # rounded outward, as the builder does
+    hi_box = np.nextafter(hi_box.astype(np.float32), F(np.inf))
+    accepted = 0
+    for first in range(0, rays, 100):
+        sl = slice(first, first + 100)
+        hb, c, disc = _quadratic(centre[None, :, :], r2[None, :], o[sl, None, :], d[sl, None, :], a[sl, None], F(1.0))
+        for tmax in (F(1e20), None):
+            if tmax is None:
+                # with a closest hit in force: the smallest accepted root of the ray
+                root, found = _roots(hb, disc, a[sl, None], F(0.001), F(1e20))
+                tmax_rays = np.where(found, root, F(np.inf)).min(axis=1)
+                tmax_rays = np.where(np.isfinite(tmax_rays), tmax_rays, F(1e20)).astype(np.float32)[:, None]
+            else:
+                tmax_rays = np.full((hb.shape[0], 1), tmax, dtype=np.float32)
+            root, found = _roots(hb, disc, a[sl, None], F(0.001), tmax_rays)
+            found &= _passes(hb, c, disc)
+            with np.errstate(invalid="ignore", over="ignore"):
+                tn, tf = _box_interval(lo_box[None, :, :], hi_box[None, :, :], inv[sl, None, :], lo_off3[sl, None, :],
+                                       hi_off3[sl, None, :])
+            inside = (tn <= root) & (root <= tf)
+            assert np.all(inside[found])
+            # and the test as the kernel applies it, with the full margin, keeps the box
+            with np.errstate(invalid="ignore", over="ignore"):
+                tn, tf = _box_interval(lo_box[None, :, :], hi_box[None, :, :], inv[sl, None, :], lo_off[sl, None, :],
+                                       hi_off[sl, None, :])
+            reached = np.maximum(tn, F(0.0)) <= np.minimum(tf, tmax_rays)
+            assert np.all(reached[found])
+            accepted += int(found.sum())
+    assert accepted > rays
 
 
 # ---------------------------------------------------------------------------------------- GPU
@@ -706,15 +809,15 @@ def test_largest_tree_kept_in_lds(pkg):
 
 @pytest.mark.gpu
 def test_largest_four_way_tree_kept_in_lds(pkg):
-    """The largest scene whose four-way tree still fits LDS (close to 2440 groups of 64 bytes beside the hash
-    tables of sixteen waves), and the first one beyond, which falls back to the depth-first tree."""
+    """The largest scene whose four-way tree still fits LDS (152 KiB beside the hash tables of sixteen waves), and the
+    first one beyond, which falls back to the depth-first tree."""
     count = 7300
     t = _host(pkg, pkg.synthetic_scene(count))
-    while len(t.get_scene_quadtree()["geom"]) == 0:
+    while t.get_scene_quadtree()["groups"] == 0:
         count -= 100
         t.set_spheres(pkg.synthetic_scene(count))
-    groups = len(t.get_scene_quadtree()["geom"])
-    assert 2000 < groups <= 2440
+    q = t.get_scene_quadtree()
+    assert 130 * 1024 < 96 * q["first_leaf"] + 64 * len(q["geom"]) <= 152 * 1024
     t.destroy()
     for n in (count, count + 100):
         scene = pkg.synthetic_scene(n)

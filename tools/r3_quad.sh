@@ -1,7 +1,7 @@
 #!/bin/bash
 # The four-way tree walk against the depth-first walk: parity tests, then timings (GPU box).
 set -e
-O=gpurun_out/r3b
+O=gpurun_out/r3c
 mkdir -p $O
 timeout -k 10 900 python -u -m pytest tests/test_hierarchy.py tests/test_fuzz_gpu.py tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q --timeout 300 --timeout-method thread > $O/pytest_quad.log 2>&1 || { tail -30 $O/pytest_quad.log; exit 1; }
 tail -3 $O/pytest_quad.log

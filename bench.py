@@ -64,8 +64,8 @@ def load_flops_per_sample(key):
 
 
 def load_hierarchy_bytes(key):
-    """LDS bytes per path sample of a workload traced through the bounding-sphere hierarchy (node visits counted by
-    the diagnostic build x 32 bytes per visit), or None."""
+    """LDS bytes per path sample of a workload traced through the hierarchy (group visits of the four-way tree of
+    boxes counted by the diagnostic build: 96 bytes per box group, 64 per group of four spheres), or None."""
     path = os.path.join(ROOT, "profiles", "flops_per_sample.json")
     with open(path) as f:
         rec = json.load(f).get(key) or {}
@@ -487,18 +487,20 @@ def main():
         }
         lds_bytes = load_hierarchy_bytes(wl["flops_key"])
         if lds_bytes is not None:
-            # The hierarchy kernel skips 99 % of the sphere tests the shader's loop makes, so the FLOP count "as
-            # written" says nothing about it (it would come out above the peak).  What bounds the walk is LDS: every
-            # node visit is a dependent 32-byte read at a per-lane address.
+            # The hierarchy kernel skips 99.9 % of the sphere tests the shader's loop makes, so the FLOP count "as
+            # written" says nothing about it (it would come out above the peak).  What the walk moves is LDS: every
+            # group visit is a read of 96 or 64 bytes at a per-lane address.
             achieved = lds_bytes * launch_samples / avg_kernel_s / 1e9
             result["roofline"] = {
                 "bound": "lds", "achieved": achieved, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": achieved / PEAK_LDS_GBPS,
                 "traffic": None, "kernel_ms": avg_kernel_s * 1e3, "lds_bytes_per_sample": lds_bytes,
                 "flops_per_sample_as_written": flops_per_sample,
-                "note": "hierarchy walk: achieved = node visits per sample (diagnostic build) x 32 B x samples per launch / "
-                        "HIP-event kernel time; peak = 256 CU x 128 B/clk x 2.4 GHz of LDS bandwidth; the walk is bound by the "
-                        "LATENCY of those dependent reads at 3 waves/SIMD (one 1024-thread workgroup per CU holds the tree), "
-                        "which is why the fraction is low; HBM traffic is negligible"}
+                "note": "hierarchy walk (four-way tree of boxes in LDS): achieved = group visits per sample (diagnostic build) "
+                        "x 96 B per box group / 64 B per group of spheres x samples per launch / HIP-event kernel time; peak = "
+                        "256 CU x 128 B/clk x 2.4 GHz of LDS bandwidth.  The fraction is low because the walk is bound by VALU "
+                        "issue at the 4 waves per SIMD its LDS footprint allows (one 1024-thread workgroup per CU holds the "
+                        "tree; profiles/r3c_c5/pmc_summary.json: 3.3 SIMD-cycles per VALU instruction at 32 of 64 lanes), "
+                        "not by LDS bytes; HBM traffic is negligible"}
         elif flops_per_sample is not None:
             achieved = flops_per_sample * launch_samples / avg_kernel_s / 1e12
             traffic, traffic_source, pmc = load_measured_traffic() if args.workload == "c2" and not distributed else (None, None, {})

@@ -63,11 +63,19 @@ def main():
         print("  %-20s %6.1f %%   %8.1f cycles/iteration" % (name, 100.0 * c / tot, c / iters))
     out["_phases"] = dict(zip(phases, [int(c) for c in cyc]))
     print("wave iterations per wave-sample: %.3f (ideal = segments per sample: 1.946 for the default scene)" % (iters / (samples / 64.0)))
-    if big:
+    if big and os.environ.get("RT_TREE_DEPTH_FIRST"):
         # every visit of a hierarchy node reads 32 bytes of LDS: the two possible successors are fetched while the node is tested
         visits = out["node"]["lane_execs"] / samples
         print("hierarchy: %.1f node visits per sample, %.0f bytes of LDS per sample at 32 bytes per visit" % (visits, 32.0 * visits))
         out["_hierarchy"] = {"node_visits_per_sample": visits, "lds_bytes_per_sample": 32.0 * visits}
+    elif big:
+        # the four-way tree: a box group is 96 bytes of LDS, a group of four spheres 64
+        boxes = out["node"]["lane_execs"] / samples
+        spheres = out["sphere_test"]["lane_execs"] / samples
+        lds = 96.0 * boxes + 64.0 * spheres
+        print("hierarchy: %.1f box groups and %.1f groups of spheres visited per sample, %.0f bytes of LDS per sample "
+              "(96 and 64 bytes per visit)" % (boxes, spheres, lds))
+        out["_hierarchy"] = {"box_groups_per_sample": boxes, "sphere_groups_per_sample": spheres, "lds_bytes_per_sample": lds}
     json.dump({"frames": frames, "samples": samples, "sections": out}, open(os.path.join(ROOT, "gpurun_out", "section_stats.json"), "w"), indent=1)
     t.destroy()
 

@@ -3,7 +3,7 @@ set -e
 mkdir -p gpurun_out/r2g
 for tile in "default" "2 3" "2 2" "1 2" "3 3" "1 1"; do
   if [ "$tile" = default ]; then unset RT_TILE_LOG2; else export RT_TILE_LOG2="$tile"; fi
-  timeout -k 10 200 python bench.py --workload c5 --mode frames --rehearse-world 8 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2g/c5_tile.json 2> gpurun_out/r2g/c5_tile.err
+  timeout -k 10 200 python bench.py --workload c5 --frames 8 --mode frames --rehearse-world 8 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2g/c5_tile.json 2> gpurun_out/r2g/c5_tile.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/r2g/c5_tile.json"))

@@ -10,7 +10,7 @@ for m in tiles frames; do
     p $O/force_distributed_${m}_${c}.json "c2 $m one-rank $c"
   done
 done
-timeout -k 10 200 python bench.py --workload c5 --mode frames --force-distributed --steps 6 --warmup 2 --no-cpu-baseline --verify > $O/force_distributed_c5_native.json 2> $O/err.log || { tail -20 $O/err.log; exit 1; }
+timeout -k 10 200 python bench.py --workload c5 --frames 8 --mode frames --force-distributed --steps 6 --warmup 2 --no-cpu-baseline --verify > $O/force_distributed_c5_native.json 2> $O/err.log || { tail -20 $O/err.log; exit 1; }
 p $O/force_distributed_c5_native.json "c5 frames one-rank native"
 timeout -k 10 200 python bench.py --workload c4 --mode tiles --force-distributed --steps 6 --warmup 2 --no-cpu-baseline --verify > $O/force_distributed_c4_native.json 2> $O/err.log || { tail -20 $O/err.log; exit 1; }
 p $O/force_distributed_c4_native.json "c4 tiles one-rank native"

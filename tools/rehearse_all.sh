@@ -10,7 +10,7 @@ for w in 8 4 2; do
   timeout -k 10 120 python bench.py --rehearse-world $w --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/r2g/rehearse_w${w}_p0.json 2> gpurun_out/r2g/err.log; p gpurun_out/r2g/rehearse_w${w}_p0.json "c2 tiles world $w"
 done
 timeout -k 10 200 python bench.py --workload c4 --rehearse-world 8 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2g/rehearse_c4_w8.json 2> gpurun_out/r2g/err.log; p gpurun_out/r2g/rehearse_c4_w8.json "c4 tiles world 8"
-timeout -k 10 200 python bench.py --workload c5 --mode frames --rehearse-world 8 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2g/rehearse_c5_w8.json 2> gpurun_out/r2g/err.log; p gpurun_out/r2g/rehearse_c5_w8.json "c5 frames world 8"
+timeout -k 10 200 python bench.py --workload c5 --frames 8 --mode frames --rehearse-world 8 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r2g/rehearse_c5_w8.json 2> gpurun_out/r2g/err.log; p gpurun_out/r2g/rehearse_c5_w8.json "c5 frames world 8"
 timeout -k 10 200 python bench.py --mode frames --rehearse-world 8 --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/r2g/rehearse_c2_frames_w8.json 2> gpurun_out/r2g/err.log; p gpurun_out/r2g/rehearse_c2_frames_w8.json "c2 frames world 8"
 for m in tiles frames; do
   timeout -k 10 200 python bench.py --force-distributed --mode $m --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2g/force_distributed_$m.json 2> gpurun_out/r2g/err.log; p gpurun_out/r2g/force_distributed_$m.json "c2 $m one-rank RCCL"

@@ -106,17 +106,17 @@ int rt_set_spheres(rt_handle h, const rt_gpu_sphere *spheres, uint32_t n);
 /* Copies out up to cap spheres of the current scene; *n receives the count. */
 int rt_get_spheres(rt_handle h, rt_gpu_sphere *out, uint32_t cap, uint32_t *n);
 
-/* Scenes of 24 spheres or more are traced through a bounding-sphere hierarchy
- * that rt_set_spheres builds: a ray is only tested against the spheres whose
- * enclosing balls it can reach, each with the arithmetic of hitSphere
+/* Scenes of 24 spheres or more are traced through a hierarchy of bounding
+ * volumes that rt_set_spheres builds: a ray is only tested against the spheres
+ * whose enclosing volumes it can reach, each with the arithmetic of hitSphere
  * (shaders/raytrace.comp.glsl:109-133), and the closest-hit rule of :247-259 is
  * kept (smallest root, the higher index on an exact tie), so images are
  * bit-identical to testing every sphere.  The reference has no counterpart (its
  * loop visits all spheres).  enable = 0 goes back to that loop; the default is 1.
- * A hierarchy that fits the GPU's on-chip memory (scenes of up to about 6000
- * spheres) is walked as a complete four-way tree of bounding boxes, four
- * children per step (rt_get_scene_quadtree); enable = 2 walks the depth-first
- * tree of balls below, one node per step, for those scenes too (same images; for
+ * The hierarchy is a complete four-way tree of bounding boxes, four children per
+ * step (rt_get_scene_quadtree), kept in the GPU's on-chip memory for scenes of up
+ * to about 6000 spheres and in global memory beyond; enable = 2 walks the
+ * depth-first tree of balls below instead, one node per step (same images; for
  * comparisons).
  * Does not raise the reset flag. */
 int rt_set_scene_hierarchy(rt_handle h, int enable);
@@ -137,8 +137,8 @@ int rt_get_scene_hierarchy_links(rt_handle h, float *geom, uint32_t *link, uint3
                                  uint32_t *n_nodes);
 
 /* The hierarchy of the current scene as the complete four-way tree that is
- * walked when it fits on chip.  The tree has *levels levels; level 0 has *roots
- * groups, every level below four times as many; the children of group g are the
+ * walked (on chip when it fits, in global memory otherwise).  The tree has
+ * *levels levels; level 0 has *roots groups, every level below four times as many; the children of group g are the
  * groups 4 g + *roots + k, k = 0..3.  Groups before *first_leaf hold the
  * axis-aligned bounding boxes of their four child groups: box receives 24 floats
  * per such group, lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4] (an unused

@@ -57,7 +57,7 @@ struct rt_tracer {
     bool use_quad = true;             // walk the four-way tree where there is one
     float4* d_quad_geom = nullptr;    // the four-way tree as the kernel stages it: six float4 per box group, then four per group of spheres
     rt_gpu_sphere* d_slot_spheres = nullptr; // the sphere list in slot order of the four-way tree
-    uint32_t d_quad_capacity = 0;     // bytes
+    size_t d_quad_capacity = 0;       // bytes
     uint32_t d_slot_capacity = 0;     // slots
     bool scene_bounded = false;       // every sphere finite, |centre| and |radius| at most 2^20
     float4* d_tree_geom = nullptr;
@@ -472,7 +472,7 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
     // fourth albedo component (all ones for an unused slot)
     const uint32_t quad_groups = index.quad.group_count();
     const uint32_t quad_slots = index.quad.slot_count();
-    const uint32_t quad_bytes = static_cast<uint32_t>(index.quad.lds_bytes());
+    const size_t quad_bytes = index.quad.lds_bytes();
     std::vector<rt_gpu_sphere> slot_spheres;
     std::vector<float> quad_image; // box groups, then the groups of spheres
     if (quad_groups != 0) {
@@ -852,7 +852,8 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
             args.tree_geom = h->d_quad_geom;
             args.tree_word = nullptr;
             args.tree_nodes = h->quad.group_count();
-            args.tree_packed = rt::kTreeFormatQuad;
+            static const bool quad_in_global = std::getenv("RT_QUAD_GLOBAL") != nullptr; // experiments: never stage the tree in LDS
+            args.tree_packed = h->quad.lds_bytes() <= rt::kQuadMaxLdsBytes && !quad_in_global ? rt::kTreeFormatQuad : rt::kTreeFormatQuadGlobal;
             args.quad_roots = h->quad.roots;
             args.quad_first_leaf = h->quad.first_leaf;
             args.quad_prologue = h->quad.prologue_spheres;

@@ -176,6 +176,7 @@ enum SceneMode {
     kTreeGlobal = 3, // hierarchy too large for LDS (or for the packed node word): walked in global memory
     kGeomGlobal = 4, // no hierarchy and too many spheres for LDS: geometry records read from global memory
     kTreeQuad = 6,   // the complete four-way tree of boxes (rt_tree.hpp: QuadTree) in LDS, four children per trip of the walk
+    kTreeQuadGlobal = 7, // the same tree, too large for LDS, walked in global memory
     kFullLds5 = 5    // kFullLds for exactly five spheres (the reference's own scene, src/rt/RayTracer.cpp:105-138):
                      // the sphere loop is unrolled and every LDS offset is a constant
 };
@@ -726,15 +727,16 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     const uint32_t sphere_count = MODE == kFullLds5 ? 5u : A.params.frame_sample_depth_count[3];
     // records ahead of the hash tables: the scene (1 or 4 float4 per sphere) or the hierarchy
     // (a float4 and a word per node)
-    constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal || MODE == kTreeQuad;
-    constexpr bool IN_GLOBAL = MODE == kTreeGlobal || MODE == kGeomGlobal; // nothing but the hash tables in LDS
+    constexpr bool QUAD = MODE == kTreeQuad || MODE == kTreeQuadGlobal;
+    constexpr bool TREE = MODE == kTree || MODE == kTreeGlobal || QUAD;
+    constexpr bool IN_GLOBAL = MODE == kTreeGlobal || MODE == kGeomGlobal || MODE == kTreeQuadGlobal; // nothing but the hash tables in LDS
     const uint32_t lds_records = IN_GLOBAL ? 0u : (MODE == kTree ? A.tree_nodes : (MODE == kTreeQuad ? 4u * A.tree_nodes + 2u * A.quad_first_leaf : sphere_count));
     float4* lds_geom = lds;
     float4* mat0 = lds + sphere_count;
     float4* mat1 = lds + 2 * sphere_count;
     float4* hit_rec = lds + 3 * sphere_count; // kFullLds only
     uint32_t* lds_word = reinterpret_cast<uint32_t*>(lds + lds_records);
-    const float4* geom = MODE == kTreeGlobal ? A.tree_geom : (MODE == kGeomGlobal ? A.loop_geom : lds_geom);
+    const float4* geom = MODE == kTreeGlobal || MODE == kTreeQuadGlobal ? A.tree_geom : (MODE == kGeomGlobal ? A.loop_geom : lds_geom);
     const uint32_t* node_word = MODE == kTreeGlobal ? A.tree_word : lds_word;
     // per-wave tables of the three hash terms of :37-44 for this unit's columns, rows and frames
     // (the seed of an item is hash(px) ^ hash(py) ^ hash(frame), :310-311)
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
         if (Stats::kEnabled && live && wave_ballot(live && depth != 0u) == 0ull) {
             st.section(ST_ALL_PRIMARY); // every ray of the wave in this iteration is a camera ray
         }
-        if (MODE == kTreeQuad) {
+        if (QUAD) {
             quad_walk(A, geom, live, ro, rd, walk, st);
             traced = live && walk.grp == kQuadIdle;
             closest = walk.closest;
@@ -1545,6 +1547,14 @@ hipError_t launch_trace(const TraceArgs& args_in, hipStream_t stream)
         }
     }
     if (args.tree_nodes != 0) {
+        if (args.tree_packed == kTreeFormatQuadGlobal) {
+            if (args.tree_geom == nullptr || args.quad_first_leaf >= args.tree_nodes || args.quad_roots == 0u ||
+                args.quad_roots > kQuadMaxRoots || args.quad_prologue > 4u) {
+                return hipErrorInvalidValue;
+            }
+            launch_trace_as<kTreeQuadGlobal, 256, kByCounter>(args, units, 4u * kWaveTableWords * 4u, stream);
+            return hipGetLastError();
+        }
         if (args.tree_packed == kTreeFormatQuad) {
             // 96 bytes per box group, 64 per group of spheres; the block size follows the footprint as below
             const size_t groups_bytes = (size_t)args.quad_first_leaf * 96u + ((size_t)args.tree_nodes - args.quad_first_leaf) * 64u;

@@ -18,7 +18,7 @@ constexpr uint32_t kMaxSpheresGeomLds = 4096;
 // Largest sphere count the tracer accepts.
 constexpr uint32_t kMaxSpheres = 1u << 20;
 
-constexpr uint32_t kTreeFormatGlobal = 0, kTreeFormatPacked = 1, kTreeFormatQuad = 2;
+constexpr uint32_t kTreeFormatGlobal = 0, kTreeFormatPacked = 1, kTreeFormatQuad = 2, kTreeFormatQuadGlobal = 3;
 
 // Kernel arguments of one trace launch.  `params` is the reference's uniform
 // block (raytrace.comp.glsl:19-31) passed by value, so it lands in scalar
@@ -43,7 +43,7 @@ struct TraceArgs {
                                   // float4 per box group, then four per group of spheres, tree_word is unused, and
                                   // `spheres` is the copy of the sphere list in slot order (one record per slot of the
                                   // last level and the prologue, the sphere's index in the bits of albedo[3],
-                                  // 0xFFFFFFFF for an unused slot)
+                                  // 0xFFFFFFFF for an unused slot); 3 = the same tree walked in global memory
     uint32_t quad_roots;          // four-way tree: groups on level 0,
     uint32_t quad_first_leaf;     // index of the first group of the last level (= number of box groups),
     uint32_t quad_prologue;       // spheres in the group behind the tree (index tree_nodes - 1), 0..4,

@@ -422,10 +422,6 @@ bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out
         tree_groups += per_level;
     }
     const uint64_t sphere_groups = tree_groups - first_leaf + 1u; // the last level and the prologue
-    if (first_leaf * 96u + sphere_groups * 64u > kQuadMaxLdsBytes) {
-        out.clear();
-        return false;
-    }
     out.first_leaf = static_cast<uint32_t>(first_leaf);
     out.prologue_spheres = outliers;
     out.box.assign(first_leaf * 24u, kQuadUnusedBox);

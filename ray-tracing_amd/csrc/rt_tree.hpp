@@ -74,7 +74,7 @@ struct SphereTree {
     }
 };
 
-// ---- a complete four-way tree of bounding boxes, for scenes whose tree fits LDS ---------------------------
+// ---- a complete four-way tree of bounding boxes (kept in LDS when it fits, in global memory otherwise) -----
 // Groups of four children, visited one group per trip of the walk: the four tests are independent, so their LDS
 // reads are in flight together and a segment's chain of dependent reads is short.  The tree is complete and
 // implicit: `roots` groups on level 0, four times as many on each level below, `levels` levels; group g of the
@@ -124,14 +124,15 @@ struct QuadTree {
 };
 constexpr uint32_t kQuadMaxRoots = 16;
 // Most bytes a four-way tree kept in LDS may take: with the hash tables of sixteen waves it has to fit the
-// 160 KiB of a compute unit.
+// 160 KiB of a compute unit.  Larger trees are walked in global memory by the same code.
 constexpr size_t kQuadMaxLdsBytes = 152u * 1024u;
-// Levels below the roots the walk's stack of pending-sibling masks (four bits per level in one register) holds.
-constexpr uint32_t kQuadMaxLevels = 9;
+// Levels below the roots the walk's stack of pending-sibling masks (four bits per level in one 32-bit register) holds.
+// Sixteen roots and eight levels below them reach 2^20 groups of the last level, four times the largest scene.
+constexpr uint32_t kQuadMaxLevels = 8;
 constexpr float kQuadUnusedBox = 3.0e38f;
 
 // Builds the four-way tree for the scenes build_sphere_tree accepts; returns false (and leaves `out` empty) for the
-// others and for trees of more than kQuadMaxLdsBytes bytes.
+// others.  out.lds_bytes() says whether the tree fits LDS (kQuadMaxLdsBytes).
 bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out);
 
 // Builds the hierarchy.  Returns false (and leaves `out` empty) when the scene does not qualify:

@@ -332,7 +332,7 @@ def _check_quad_structure(scene, q):
     assert first_leaf == sum(per_level[:-1]) == len(box)
     assert len(geom) == groups - first_leaf
     assert len(slot_sphere) == 4 * (groups - first_leaf)
-    assert 96 * first_leaf + 64 * len(geom) <= 152 * 1024           # what the kernel stages in LDS
+    assert levels <= 9                                              # four bits of pending siblings per level below the roots
     used = slot_sphere != NONE
     assert sorted(slot_sphere[used].tolist()) == list(range(len(scene)))     # every sphere in exactly one slot
     leaf_geom = geom.reshape(-1, 4)
@@ -374,10 +374,12 @@ def _check_quad_structure(scene, q):
     assert 0.0 < q["min_radius"] <= r.min()
 
 
-@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "synthetic24", "synthetic4097", "random", "clusters"])
+@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "synthetic24", "synthetic4097", "synthetic20000", "random",
+                                  "clusters"])
 def test_quadtree_structure(pkg, name):
     scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "synthetic100": lambda: pkg.synthetic_scene(100),
              "synthetic24": lambda: pkg.synthetic_scene(24), "synthetic4097": lambda: pkg.synthetic_scene(4097),
+             "synthetic20000": lambda: pkg.synthetic_scene(20000),
              "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
     q = _quad(pkg, scene)
     assert q["groups"] > 0
@@ -398,8 +400,9 @@ def test_scenes_without_quadtree(pkg):
     scene[77, 0] = np.nan
     t.set_spheres(scene)
     assert t.get_scene_quadtree()["groups"] == 0
-    t.set_spheres(pkg.synthetic_scene(9000))                  # does not fit LDS: only the depth-first tree exists
-    assert t.get_scene_quadtree()["groups"] == 0
+    t.set_spheres(pkg.synthetic_scene(9000))                  # does not fit LDS: the same kind of tree, walked in global memory
+    q = t.get_scene_quadtree()
+    assert q["groups"] > 0 and 96 * q["first_leaf"] + 64 * len(q["geom"]) > 152 * 1024
     assert len(t.get_scene_hierarchy_links()[1]) > 0
     t.destroy()
 
@@ -499,23 +502,25 @@ def _quad_walk_closest(q, scene, o, d):
     return out_closest, out_best, visits
 
 
-@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "random", "clusters"])
+@pytest.mark.parametrize("name", ["synthetic4096", "synthetic100", "synthetic20000", "random", "clusters"])
 def test_quad_walk_finds_the_hit_of_the_loop_over_all_spheres(pkg, name):
     """The walk of the four-way tree ends with the same root and the same sphere as the loop of :247-259
     (smallest accepted root; of equal roots the highest index), for camera-like, surface-born, far-away and
     grazing rays of assorted lengths."""
     scene = {"synthetic4096": lambda: pkg.synthetic_scene(4096), "synthetic100": lambda: pkg.synthetic_scene(100),
+             "synthetic20000": lambda: pkg.synthetic_scene(20000),
              "random": pkg.random_scene, "clusters": lambda: _cluster_scene(pkg)}[name]()
     q = _quad(pkg, scene)
-    rays = 400 if name == "synthetic4096" else 800
+    rays = 400 if len(scene) > 1000 else 800
     o, d = _rays(scene, rays, seed=29)
     a = _dot(d, d)
     closest, best, visits = _quad_walk_closest(q, scene, o, d)
     centre = scene[:, :3]
     r2 = scene[:, 3] * scene[:, 3]
     hits = 0
-    for lo in range(0, rays, 200):
-        sl = slice(lo, lo + 200)
+    step = 50 if len(scene) > 10000 else 200
+    for lo in range(0, rays, step):
+        sl = slice(lo, lo + step)
         hb, c, disc = _quadratic(centre[None, :, :], r2[None, :], o[sl, None, :], d[sl, None, :], a[sl, None], F(1.0))
         root, found = _roots(hb, disc, a[sl, None], F(0.001), F(1e20))
         root = np.where(found, root, F(np.inf))
@@ -810,14 +815,16 @@ def test_largest_tree_kept_in_lds(pkg):
 @pytest.mark.gpu
 def test_largest_four_way_tree_kept_in_lds(pkg):
     """The largest scene whose four-way tree still fits LDS (152 KiB beside the hash tables of sixteen waves), and the
-    first one beyond, which falls back to the depth-first tree."""
+    first one beyond, whose tree is walked in global memory."""
+    def tree_bytes(q):
+        return 96 * q["first_leaf"] + 64 * len(q["geom"])
+
     count = 7300
     t = _host(pkg, pkg.synthetic_scene(count))
-    while t.get_scene_quadtree()["groups"] == 0:
+    while tree_bytes(t.get_scene_quadtree()) > 152 * 1024:
         count -= 100
         t.set_spheres(pkg.synthetic_scene(count))
-    q = t.get_scene_quadtree()
-    assert 130 * 1024 < 96 * q["first_leaf"] + 64 * len(q["geom"]) <= 152 * 1024
+    assert 130 * 1024 < tree_bytes(t.get_scene_quadtree())
     t.destroy()
     for n in (count, count + 100):
         scene = pkg.synthetic_scene(n)

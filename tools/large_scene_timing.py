@@ -28,8 +28,10 @@ def main():
         t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
         row = {"set_spheres_ms": build_ms, "nodes": int(t.get_scene_hierarchy_links()[1].shape[0])}
         images = {}
-        for name, enable in (("hierarchy", True), ("loop", False)):
-            if not enable and n > 20000:
+        row["tree_groups"] = int(t.get_scene_quadtree()["groups"])
+        # hierarchy: the four-way tree of boxes (in LDS or in global memory); depth_first: the tree of balls, one node per trip
+        for name, enable in (("hierarchy", True), ("depth_first", 2), ("loop", False)):
+            if enable is False and n > 20000:
                 continue
             t.set_scene_hierarchy(enable)
             for _ in range(2):
@@ -38,8 +40,7 @@ def main():
                 t.synchronize()
             row[name + "_ms"] = t.last_kernel_ms()
             images[name] = t.read_accum()
-        if len(images) == 2:
-            row["identical"] = bool(np.array_equal(images["loop"].view(np.uint32), images["hierarchy"].view(np.uint32)))
+        row["identical"] = all(bool(np.array_equal(images["hierarchy"].view(np.uint32), im.view(np.uint32))) for im in images.values())
         out[n] = row
         print(n, json.dumps(row), flush=True)
         t.destroy()

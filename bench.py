@@ -295,9 +295,25 @@ def main():
 
     stripe_rows = args.stripe_rows or (16 if height >= 4000 else 4)
     native = None
+    native_error = None
     if distributed and not rehearse and args.backend == "nccl" and args.collectives == "native":
-        from raytracing_amd import rccl as rtrccl
-        native = rtrccl.Communicator(rtrccl.unique_id_over_torch(rank, device), world, rank, device_id=device_index)
+        # The library's own communicator.  If any rank cannot set it up (library missing, ncclCommInitRank refused),
+        # every rank falls back to the torch.distributed collectives together, and the line says so.
+        try:
+            from raytracing_amd import rccl as rtrccl
+            rtrccl.load_library()
+            native = rtrccl.Communicator(rtrccl.unique_id_over_torch(rank, device), world, rank, device_id=device_index)
+        except Exception as e:  # noqa: BLE001 -- whatever it was, the other path still measures the job
+            native_error = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if native is not None:
+                native.destroy()
+                native = None
+            native_error = native_error or "another rank could not create the communicator"
+            if rank == 0:
+                print("bench.py: native collectives unavailable (%s); using torch.distributed" % native_error, file=sys.stderr)
     accum = rtdist.accum_tensor(tracer, device) if distributed else None
     # The collective of a step runs on a side stream, and the rendering stream never waits for that stream: the
     # rank's shard is copied out of the accumulator on the rendering stream itself (into one of two staging
@@ -461,7 +477,8 @@ def main():
             how = ("interleaved %d-row stripes x%d + RCCL all-gather of the accumulator" % (stripe_rows, split_world)
                    if args.mode == "tiles" else "frame-index split x%d + RCCL sum all-reduce of the accumulator" % split_world)
             how += (" (librt_mi355x_rccl.so: native pack/unpack kernels, ncclAllGather/ncclAllReduce)" if native is not None
-                    else " (torch.distributed, backend %s)" % args.backend)
+                    else " (torch.distributed, backend %s%s)" % (args.backend, "; native collectives unavailable: " + native_error
+                                                                  if native_error else ""))
             if rehearse:
                 how = ("REHEARSAL ON ONE GPU, not a measurement of %d GPUs: rank 0's part of [%s], the collective replaced by "
                        "device copies of the same size; value = what %d ranks would reach if each took as long"

@@ -28,11 +28,12 @@
 // own pixel tile test only the spheres that tile can see; the kernel for exactly five spheres (the
 // reference's scene) has its sphere loop unrolled.
 //
-// Scenes of kTreeMinSpheres spheres or more are traced through a bounding-sphere hierarchy
-// (rt_tree.hpp): each lane walks the depth-first node array on its own, one node per trip, and a
-// leaf goes through the same arithmetic as in the plain loop.  A lane's walk may stretch over several
-// iterations of the trace loop (tree_walk), and the waves of that kernel take their units from a
-// counter in memory.  Trees too large for LDS are walked in global memory.
+// Scenes of kTreeMinSpheres spheres or more are traced through a hierarchy (rt_tree.hpp): a complete
+// four-way tree of bounding boxes that each lane walks on its own, four children per trip (quad_walk);
+// a sphere it reaches goes through the same arithmetic as in the plain loop.  A lane's walk may stretch
+// over several iterations of the trace loop, and the waves of that kernel take their units from a
+// counter in memory.  Trees too large for LDS are walked in global memory.  (tree_walk walks the older
+// depth-first tree of bounding balls, one node per trip, on request.)
 //
 // Compile with -ffp-contract=off (see rt_device.hpp).
 #include "rt_device.hpp"

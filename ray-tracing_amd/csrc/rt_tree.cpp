@@ -219,7 +219,7 @@ bool collect_items(const rt_gpu_sphere* spheres, uint32_t count, std::vector<Ite
 //    box is beyond the closest hit so far) can hold for a box that contains the sphere.  NaN cannot arise: every
 //    operand is finite (unused children are boxes at 3e38, beyond every ray of the range, not infinities).
 struct QuadBuilder {
-    Builder balls;   // its items
+    std::vector<Item> items;
     QuadTree* out;
     const rt_gpu_sphere* spheres;
 
@@ -230,7 +230,6 @@ struct QuadBuilder {
         if (count == 0 || lo + count >= hi) {
             return;
         }
-        std::vector<Item>& items = balls.items;
         double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
         for (uint32_t i = lo; i < hi; ++i) {
             for (int k = 0; k < 3; ++k) {
@@ -263,7 +262,6 @@ struct QuadBuilder {
     // Child k of box group `group`: the box around items[lo, hi).
     void set_box(uint32_t group, uint32_t k, uint32_t lo, uint32_t hi)
     {
-        const std::vector<Item>& items = balls.items;
         double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
         for (uint32_t i = lo; i < hi; ++i) {
             for (int a = 0; a < 3; ++a) {
@@ -283,10 +281,10 @@ struct QuadBuilder {
     {
         const uint32_t rel = group - out->first_leaf;
         for (uint32_t i = lo; i < hi; ++i) {
-            const float* cr = spheres[balls.items[i].index].center_radius;
+            const float* cr = spheres[items[i].index].center_radius;
             const float g[4] = { cr[0], cr[1], cr[2], cr[3] * cr[3] }; // the product the loop over all spheres uses
             std::copy(g, g + 4, out->geom.begin() + (static_cast<size_t>(rel) * 4u + (i - lo)) * 4u);
-            out->slot_sphere[4u * rel + (i - lo)] = balls.items[i].index;
+            out->slot_sphere[4u * rel + (i - lo)] = items[i].index;
         }
     }
 
@@ -332,7 +330,6 @@ struct QuadBuilder {
     // The ball around items[lo, hi) and their smallest radius, for the walk's margin.
     void set_bounds(uint32_t lo, uint32_t hi)
     {
-        const std::vector<Item>& items = balls.items;
         double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
         double r_min = 1e300;
         for (uint32_t i = lo; i < hi; ++i) {
@@ -369,8 +366,7 @@ bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out
     QuadBuilder b;
     b.out = &out;
     b.spheres = spheres;
-    b.balls.out = nullptr;
-    std::vector<Item>& items = b.balls.items;
+    std::vector<Item>& items = b.items;
     if (!collect_items(spheres, count, items)) {
         return false;
     }

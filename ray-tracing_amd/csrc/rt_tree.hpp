@@ -1,5 +1,7 @@
-// Bounding-sphere hierarchy over a sphere list, for scenes where testing every sphere against
-// every ray segment (the loop of shaders/raytrace.comp.glsl:247-259) dominates the run time.
+// Hierarchies over a sphere list, for scenes where testing every sphere against every ray segment
+// (the loop of shaders/raytrace.comp.glsl:247-259) dominates the run time: a depth-first tree of
+// bounding balls (SphereTree, described first; walked on request only) and the complete four-way tree
+// of bounding boxes that the tracer uses (QuadTree, further down).
 //
 // The hierarchy only decides WHICH spheres a ray is tested against; every sphere that is tested
 // goes through exactly the arithmetic of hitSphere (:109-133), and the closest-hit rule of

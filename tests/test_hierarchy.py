@@ -164,7 +164,7 @@ def _rays(scene, count, seed):
     o = np.zeros((count, 3), dtype=np.float32)
     d = np.zeros((count, 3), dtype=np.float32)
     for i in range(count):
-        kind = i % 5
+        kind = i % 6
         s = scene[rng.integers(0, len(scene))]
         target = s[:3] + rng.normal(size=3) * s[3]
         if kind == 0:      # from a camera position
@@ -183,9 +183,25 @@ def _rays(scene, count, seed):
             side = np.cross(to, rng.normal(size=3))
             side /= np.linalg.norm(side)
             target = s[:3] + side * s[3] * (1.0 + rng.normal() * 1e-6)
-        else:              # from inside a cluster, any direction
+        elif kind == 4:    # from inside a cluster, any direction
             origin = s[:3] + rng.normal(size=3) * 2.0
             target = origin + rng.normal(size=3)
+        else:              # parallel to one or two axes (zero components of either sign), along a face of a sphere's
+            # bounding box or through its centre: the slab test divides by these components
+            axes = rng.permutation(3)[:int(rng.integers(1, 3))]
+            offset = np.zeros(3)
+            for k in range(3):
+                if k not in axes:
+                    offset[k] = s[3] * rng.choice([-1.0, 0.0, 1.0, rng.normal()])
+            origin = s[:3].astype(np.float64) + offset
+            direction = np.zeros(3)
+            for k in axes:
+                direction[k] = rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-2.0, 2.0)
+                origin[k] -= direction[k] / abs(direction[k]) * (s[3] + 10.0 ** rng.uniform(-1.0, 1.5))
+            o[i] = origin
+            d[i] = direction * rng.choice([1.0, 1.0, -1.0])          # some point away from the sphere
+            d[i][d[i] == 0.0] = rng.choice([0.0, -0.0], size=int((d[i] == 0.0).sum()))
+            continue
         direction = target - origin
         direction *= 10.0 ** rng.uniform(-2.0, 2.0) / np.linalg.norm(direction)
         o[i] = origin

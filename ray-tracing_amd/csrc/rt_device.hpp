@@ -465,7 +465,12 @@ __device__ __forceinline__ void sphere_closest_any_order(const SphereQuadratic& 
     st.section(5 /* ST_ROOT */);
     const float sqrt_disc = sqrt_exact(q.discriminant);
     float root = root_div(-q.half_b - sqrt_disc, rden);
-    if (root < tmin || root > closest) {
+    if (root > closest) {
+        // The far root is no smaller than the near one (the square root is >= 0 and a correctly rounded division by
+        // a > 0 is monotonic), so :127-129 would reject it as well: a sphere behind the closest hit costs one root.
+        return;
+    }
+    if (root < tmin) {
         st.section(6 /* ST_FAR_ROOT */);
         root = root_div(-q.half_b + sqrt_disc, rden);
         if (root < tmin || root > closest) {

@@ -13,11 +13,15 @@ sys.path.insert(0, ROOT)
 def main():
     import rtamd_loader
     pkg = rtamd_loader.load()
-    for name, spp, depth, aperture in (("c2 settings", 16, 8, 0.0), ("application defaults", 4, 12, 0.05), ("1 spp", 1, 8, 0.05)):
+    for name, spp, depth, aperture in (("c2 settings", 16, 8, 0.0), ("application defaults", 4, 12, 0.05), ("1 spp", 1, 8, 0.05),
+                                       ("4096 spheres, c5", 16, 50, 0.05), ("4096 spheres, 4 spp", 4, 12, 0.05)):
         t = pkg.RayTracer().create(1920, 1080, device_id=0)
         t.set_samples_per_pixel(spp)
         t.set_max_depth(depth)
         t.set_aperture(aperture)
+        if name.startswith("4096"):
+            t.set_spheres(pkg.synthetic_scene(4096))
+            t.set_camera([3.0, 1.5, 6.0], [-0.4, -0.2, -1.0], 6.0)
         frames = 64
         best = 1e9
         for rep in range(3):

@@ -94,6 +94,19 @@ def load_measured_traffic():
     return best, source, derived
 
 
+def load_workload_pmc(workload):
+    """Per-launch figures of the committed rocprofv3 PMC passes of another workload (profiles/r<round><letter>_<workload>/),
+    the most recent one, with the file they were read from; ({}, None) if there is none."""
+    import re
+    derived, source = {}, None
+    base = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(base)):
+        path = os.path.join(base, name, "pmc_summary.json")
+        if re.fullmatch(r"r\d+[a-z]*_" + re.escape(workload), name) and os.path.isfile(path):
+            derived, source = json.load(open(path)).get("_derived", {}), os.path.relpath(path, ROOT)
+    return derived, source
+
+
 def host_threads():
     """Threads for the CPU baseline: every core this process may run on (its affinity mask; the machine's
     core count can be many times that on a shared box), bounded by OMP_NUM_THREADS where the environment
@@ -510,10 +523,15 @@ def main():
             # written" says nothing about it (it would come out above the peak).  What the walk moves is LDS: every
             # group visit is a read of 96 or 64 bytes at a per-lane address.
             achieved = lds_bytes * launch_samples / avg_kernel_s / 1e9
+            pmc, pmc_source = load_workload_pmc(args.workload)
             result["roofline"] = {
                 "bound": "lds", "achieved": achieved, "peak": PEAK_LDS_GBPS, "unit": "GB/s", "frac": achieved / PEAK_LDS_GBPS,
                 "traffic": None, "kernel_ms": avg_kernel_s * 1e3, "lds_bytes_per_sample": lds_bytes,
                 "flops_per_sample_as_written": flops_per_sample,
+                "valu": {"insts_per_wave_sample": pmc.get("valu_insts_per_wave_sample"),
+                         "lanes_per_inst": pmc.get("mean_active_lanes_per_valu_inst"),
+                         "simd_cycles_per_valu_inst": pmc.get("simd_cycles_per_valu_inst"),
+                         "waves_per_simd": pmc.get("mean_waves_per_simd"), "source": pmc_source},
                 "note": "hierarchy walk (four-way tree of boxes in LDS): achieved = group visits per sample (diagnostic build) "
                         "x 96 B per box group / 64 B per group of spheres x samples per launch / HIP-event kernel time; peak = "
                         "256 CU x 128 B/clk x 2.4 GHz of LDS bandwidth.  The fraction is low because the walk is bound by VALU "

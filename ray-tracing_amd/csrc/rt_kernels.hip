@@ -494,15 +494,17 @@ __device__ __forceinline__ void sphere_closest_slot(const SphereQuadratic& q, co
 
 // One child of a box group against the ray: whether the parameter interval inside the box, grown by the ray's
 // margin, reaches into [0, closest].  lo/hi are the child's bounds on the three axes; the arithmetic and why
-// its rounding is harmless are described in rt_tree.cpp.
-__device__ __forceinline__ bool box_reached(float lx, float ly, float lz, float hx, float hy, float hz, const TreeWalk& t)
+// its rounding is harmless are described in rt_tree.cpp.  Returns a key for choosing the child to visit first:
+// the bits of the entry parameter (>= 0, so they order like the floats) with the child's number k in the two lowest
+// bits, or all ones for a child the ray does not reach.
+__device__ __forceinline__ uint32_t box_reached(float lx, float ly, float lz, float hx, float hy, float hz, const TreeWalk& t, uint32_t k)
 {
     const float ax = __builtin_fmaf(lx, t.inv.x, t.lo_off.x), bx = __builtin_fmaf(hx, t.inv.x, t.hi_off.x);
     const float ay = __builtin_fmaf(ly, t.inv.y, t.lo_off.y), by = __builtin_fmaf(hy, t.inv.y, t.hi_off.y);
     const float az = __builtin_fmaf(lz, t.inv.z, t.lo_off.z), bz = __builtin_fmaf(hz, t.inv.z, t.hi_off.z);
     const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
     const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), t.closest);
-    return tn <= tf;
+    return tn <= tf ? ((__float_as_uint(tn) & ~3u) | k) : 0xFFFFFFFFu;
 }
 
 // Walk of the complete four-way tree (rt_tree.hpp: QuadTree), resumable like tree_walk.  One trip = one group
@@ -576,14 +578,19 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
             st.section(ST_NODE);
             const float4* b = tree + 6u * t.grp;
             const float4 lx = b[0], ly = b[1], lz = b[2], hx = b[3], hy = b[4], hz = b[5];
-            const uint32_t pass = (box_reached(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t) ? 1u : 0u) |
-                                  (box_reached(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t) ? 2u : 0u) |
-                                  (box_reached(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t) ? 4u : 0u) |
-                                  (box_reached(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t) ? 8u : 0u);
+            const uint32_t k0 = box_reached(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t, 0u);
+            const uint32_t k1 = box_reached(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t, 1u);
+            const uint32_t k2 = box_reached(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t, 2u);
+            const uint32_t k3 = box_reached(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t, 3u);
+            const uint32_t pass = (k0 != 0xFFFFFFFFu ? 1u : 0u) | (k1 != 0xFFFFFFFFu ? 2u : 0u) | (k2 != 0xFFFFFFFFu ? 4u : 0u) |
+                                  (k3 != 0xFFFFFFFFu ? 8u : 0u);
             if (pass != 0u) {
-                // down to the first child that passed; the others wait
-                t.stack = (t.stack << 4) | (pass & (pass - 1u));
-                t.grp = 4u * t.grp + roots + (uint32_t)__builtin_ctz(pass);
+                // Down to the child the ray enters first (a hit found there spares the walk the children behind it);
+                // the others wait, and are visited in the order of their numbers.  The order of the visits does not
+                // change the result (sphere_closest_slot).
+                const uint32_t first = min(min(k0, k1), min(k2, k3)) & 3u;
+                t.stack = (t.stack << 4) | (pass & ~(1u << first));
+                t.grp = 4u * t.grp + roots + first;
             } else {
                 done_here = true;
             }

@@ -451,8 +451,8 @@ def _box_interval(lo, hi, inv, lo_off, hi_off):
 
 def _quad_walk_closest(q, scene, o, d):
     """The kernel's walk of the four-way tree in float32, ray by ray: prologue spheres first, four boxes per visited
-    group, pending siblings as four bits per level, spheres of a last-level group resolved in slot order with ties
-    going to the higher sphere index."""
+    group, down to the child the ray enters first, pending siblings as four bits per level, spheres of a last-level
+    group resolved in slot order with ties going to the higher sphere index."""
     box, geom, slot_sphere = q["box"], q["geom"], q["slot_sphere"]
     roots, first_leaf, groups = q["roots"], q["first_leaf"], q["groups"]
     rays = o.shape[0]
@@ -489,11 +489,15 @@ def _quad_walk_closest(q, scene, o, d):
                 lo, hi = box[grp, 0:3, :].T, box[grp, 3:6, :].T          # (child, axis)
                 with np.errstate(invalid="ignore", over="ignore"):
                     tn, tf = _box_interval(lo, hi, inv[None, :], lo_off[None, :], hi_off[None, :])
-                ok = np.maximum(tn, F(0.0)) <= np.minimum(tf, state["closest"])
+                enter = np.maximum(tn, F(0.0))
+                ok = enter <= np.minimum(tf, state["closest"])
                 mask = int(sum(1 << k for k in range(4) if ok[k]))
                 if mask:
-                    k = (mask & -mask).bit_length() - 1
-                    stack = (stack << 4) | (mask & (mask - 1))
+                    # first the child the ray enters first (the kernel's key: the bits of the entry parameter with
+                    # the child's number in the two lowest), the others in the order of their numbers
+                    keys = [((int(enter[k].view(np.uint32)) & ~3) | k) if ok[k] else 0xFFFFFFFF for k in range(4)]
+                    k = min(keys) & 3
+                    stack = (stack << 4) | (mask & ~(1 << k))
                     assert stack < 2 ** 32
                     grp = 4 * grp + roots + k
                 else:

@@ -4,7 +4,7 @@
 # launches (units of 8 pixels x 4 frames by default) against larger units.
 # Results: gpurun_out/r3a/*.json.   Usage (GPU box): bash tools/r3_c5_frames.sh
 set -e
-O=gpurun_out/r3d
+O=gpurun_out/r3h
 mkdir -p $O
 p() { python -c "import json,sys; d=json.load(open('$1')); print('$2', 'ms_per_step %.3f value %.4e kernel_ms %.3f' % (d['ms_per_step'], d['value'], d['roofline']['kernel_ms']))"; }
 for f in 8 32 64; do

@@ -370,13 +370,16 @@ bool build_quad_tree(const rt_gpu_sphere* spheres, uint32_t count, QuadTree& out
     if (!collect_items(spheres, count, items)) {
         return false;
     }
-    // Spheres more than sixteen times the median radius: the (up to four) largest go into the prologue.
+    // Spheres more than four times the median radius: the (up to four) largest go into the prologue.  Measured on
+    // the random scene (485 spheres, three of radius 1 among spheres of radius 0.2, and the ground): with a factor of
+    // sixteen only the ground is kept out and the three large spheres widen the boxes above them, 13.6 ms; with four
+    // they are tested with the ground at the start of every segment, 11.9 ms.
     std::vector<double> radii(count);
     for (uint32_t i = 0; i < count; ++i) {
         radii[i] = items[i].r;
     }
     std::nth_element(radii.begin(), radii.begin() + count / 2u, radii.end());
-    const double big = 16.0 * radii[count / 2u];
+    const double big = 4.0 * radii[count / 2u];
     std::stable_sort(items.begin(), items.end(), [&](const Item& x, const Item& y) {
         const bool bx = x.r > big, by = y.r > big;
         return bx != by ? bx : (bx && x.r != y.r ? x.r > y.r : false);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round check on the GPU box: smoke, the whole GPU suite, the bench line, the one-rank native collective path, C5 line.
 set -e
-O=gpurun_out/r3g
+O=gpurun_out/r3i
 mkdir -p $O
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }

@@ -54,7 +54,8 @@ struct rt_tracer {
     rt::SphereTree tree;              // hierarchy over `spheres` (empty for small or out-of-range scenes)
     rt::QuadTree quad;                // the same as a complete four-way tree, when that fits LDS (else empty)
     bool use_tree = true;
-    bool use_quad = true;             // walk the four-way tree where there is one
+    bool use_quad = true;             // walk the four-way tree of boxes (false: the depth-first tree of balls)
+    bool tree_on_device = false;      // d_tree_geom / d_tree_word hold `tree` of the current scene
     float4* d_quad_geom = nullptr;    // the four-way tree as the kernel stages it: six float4 per box group, then four per group of spheres
     rt_gpu_sphere* d_slot_spheres = nullptr; // the sphere list in slot order of the four-way tree
     size_t d_quad_capacity = 0;       // bytes
@@ -393,7 +394,9 @@ struct SceneIndex {
     rt::QuadTree quad;
 };
 
-void index_scene(const std::vector<rt_gpu_sphere>& spheres, SceneIndex& out)
+// want_depth_first: also build the older depth-first tree of balls (needed only when the handle walks that tree;
+// otherwise it is built when somebody asks for it, ensure_depth_first_tree).
+void index_scene(const std::vector<rt_gpu_sphere>& spheres, bool want_depth_first, SceneIndex& out)
 {
     out.bounded = true;
     for (const rt_gpu_sphere& s : spheres) {
@@ -403,8 +406,44 @@ void index_scene(const std::vector<rt_gpu_sphere>& spheres, SceneIndex& out)
             }
         }
     }
-    (void)rt::build_sphere_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.tree); // empty when the scene does not qualify
-    (void)rt::build_quad_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.quad);   // empty as well when it would not fit LDS
+    (void)rt::build_quad_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.quad); // empty when the scene does not qualify
+    if (want_depth_first && !out.quad.empty()) {
+        (void)rt::build_sphere_tree(spheres.data(), static_cast<uint32_t>(spheres.size()), out.tree);
+    }
+}
+
+// The depth-first tree as the kernels read it.  The node arrays hold one entry more than the tree has nodes: the
+// walk fetches the node behind the one it is testing, also behind the last.  Words: one per node (packed) or two (wide).
+void pack_depth_first_tree(const rt::SphereTree& tree, std::vector<float>& tree_geom, std::vector<uint32_t>& tree_words)
+{
+    const uint32_t nodes = tree.node_count();
+    tree_geom.clear();
+    tree_words.clear();
+    if (nodes == 0) {
+        return;
+    }
+    tree_geom = tree.geom;
+    tree_geom.resize((static_cast<size_t>(nodes) + 1u) * 4u, 0.0f);
+    if (tree.packed()) {
+        tree_words = tree.word;
+        tree_words.push_back(0u);
+        // the LDS walk reads an inner node's continuation from its fourth float: sign bit set, the
+        // value rounded up to a multiple of 2^13 ulps, the node index in the 13 bits that frees
+        for (uint32_t i = 0; i < nodes; ++i) {
+            if (tree.sphere[i] == rt::kTreeNoSphere) {
+                uint32_t bits;
+                std::memcpy(&bits, &tree_geom[4u * i + 3u], sizeof bits);
+                bits = ((bits + 0x1FFFu) & ~0x1FFFu) | tree.link[i] | 0x80000000u;
+                std::memcpy(&tree_geom[4u * i + 3u], &bits, sizeof bits);
+            }
+        }
+    } else {
+        tree_words.resize((static_cast<size_t>(nodes) + 1u) * 2u, 0u);
+        for (uint32_t i = 0; i < nodes; ++i) {
+            tree_words[2u * i] = tree.link[i] * 16u;
+            tree_words[2u * i + 1u] = tree.sphere[i] == rt::kTreeNoSphere ? 0u : rt::kTreeLeafFlag | tree.sphere[i];
+        }
+    }
 }
 
 // A device buffer that is either the handle's current one (large enough) or a fresh allocation
@@ -430,44 +469,20 @@ struct Staged {
 int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
 {
     SceneIndex index;
-    index_scene(spheres, index);
+    index_scene(spheres, !h->use_quad, index);
     if (h->device < 0) {
         h->spheres = std::move(spheres);
         h->tree = std::move(index.tree);
+        h->tree_on_device = false;
         h->quad = std::move(index.quad);
         h->scene_bounded = index.bounded;
         return RT_OK;
     }
     const uint32_t n = static_cast<uint32_t>(spheres.size());
-    // The node arrays hold one entry more than the tree has nodes: the walk fetches the node behind
-    // the one it is testing, also behind the last.  Words: one per node (packed) or two (wide).
     const uint32_t nodes = index.tree.node_count();
     std::vector<float> tree_geom;
     std::vector<uint32_t> tree_words;
-    if (nodes != 0) {
-        tree_geom = index.tree.geom;
-        tree_geom.resize((static_cast<size_t>(nodes) + 1u) * 4u, 0.0f);
-        if (index.tree.packed()) {
-            tree_words = index.tree.word;
-            tree_words.push_back(0u);
-            // the LDS walk reads an inner node's continuation from its fourth float: sign bit set, the
-            // value rounded up to a multiple of 2^13 ulps, the node index in the 13 bits that frees
-            for (uint32_t i = 0; i < nodes; ++i) {
-                if (index.tree.sphere[i] == rt::kTreeNoSphere) {
-                    uint32_t bits;
-                    std::memcpy(&bits, &tree_geom[4u * i + 3u], sizeof bits);
-                    bits = ((bits + 0x1FFFu) & ~0x1FFFu) | index.tree.link[i] | 0x80000000u;
-                    std::memcpy(&tree_geom[4u * i + 3u], &bits, sizeof bits);
-                }
-            }
-        } else {
-            tree_words.resize((static_cast<size_t>(nodes) + 1u) * 2u, 0u);
-            for (uint32_t i = 0; i < nodes; ++i) {
-                tree_words[2u * i] = index.tree.link[i] * 16u;
-                tree_words[2u * i + 1u] = index.tree.sphere[i] == rt::kTreeNoSphere ? 0u : rt::kTreeLeafFlag | index.tree.sphere[i];
-            }
-        }
-    }
+    pack_depth_first_tree(index.tree, tree_geom, tree_words);
     // the four-way tree: its groups, and the sphere records in slot order with the sphere's index in the unused
     // fourth albedo component (all ones for an unused slot)
     const uint32_t quad_groups = index.quad.group_count();
@@ -508,6 +523,8 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
         if (nodes != 0) {
             RT_HIP_TRY(h, d_tree_geom.take(h->d_tree_geom, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * sizeof(float4)));
             RT_HIP_TRY(h, d_tree_word.take(h->d_tree_word, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * 2u * sizeof(uint32_t)));
+        }
+        if (nodes != 0 || quad_groups != 0) {
             RT_HIP_TRY(h, d_counter.take(h->d_unit_counter, 1, 1, 64u * (1u + rt_tracer::kPipeSlots)));
         }
         if (!loop_geom.empty()) {
@@ -590,8 +607,60 @@ int install_scene(rt_tracer* h, std::vector<rt_gpu_sphere>&& spheres)
     }
     h->spheres = std::move(spheres);
     h->tree = std::move(index.tree);
+    h->tree_on_device = nodes != 0;
     h->quad = std::move(index.quad);
     h->scene_bounded = index.bounded;
+    return RT_OK;
+}
+
+// The depth-first tree of balls of the current scene, built when it is first asked for (the tracer walks the
+// four-way tree of boxes; the older tree serves comparisons, rt_set_scene_hierarchy(h, 2), and its getters).
+// on_device: also put it on the handle's device.  A failure leaves the handle as it was.
+int ensure_depth_first_tree(rt_tracer* h, bool on_device)
+{
+    if (h->quad.empty()) {
+        return RT_OK; // the scene has no hierarchy of either kind
+    }
+    rt::SphereTree built;
+    const rt::SphereTree* tree = &h->tree;
+    if (h->tree.empty()) {
+        (void)rt::build_sphere_tree(h->spheres.data(), static_cast<uint32_t>(h->spheres.size()), built);
+        tree = &built;
+    }
+    if (on_device && h->device >= 0 && !h->tree_on_device && !tree->empty()) {
+        const uint32_t nodes = tree->node_count();
+        std::vector<float> tree_geom;
+        std::vector<uint32_t> tree_words;
+        pack_depth_first_tree(*tree, tree_geom, tree_words);
+        DeviceScope scope(h->device);
+        RT_HIP_TRY(h, scope.status());
+        RT_HIP_TRY(h, wait_for_renders(h)); // buffers of an earlier scene may be replaced
+        Staged d_tree_geom, d_tree_word;
+        auto body = [&]() -> int {
+            RT_HIP_TRY(h, d_tree_geom.take(h->d_tree_geom, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * sizeof(float4)));
+            RT_HIP_TRY(h, d_tree_word.take(h->d_tree_word, h->d_tree_capacity, nodes, (static_cast<size_t>(nodes) + 1u) * 2u * sizeof(uint32_t)));
+            RT_HIP_TRY(h, hipMemcpy(d_tree_geom.ptr, tree_geom.data(), tree_geom.size() * sizeof(float), hipMemcpyHostToDevice));
+            RT_HIP_TRY(h, hipMemcpy(d_tree_word.ptr, tree_words.data(), tree_words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            return RT_OK;
+        };
+        const int rc = body();
+        if (rc != RT_OK) {
+            d_tree_geom.drop();
+            d_tree_word.drop();
+            return rc;
+        }
+        if (d_tree_geom.fresh || d_tree_word.fresh) {
+            if (h->d_tree_geom && d_tree_geom.fresh) { (void)hipFree(h->d_tree_geom); }
+            if (h->d_tree_word && d_tree_word.fresh) { (void)hipFree(h->d_tree_word); }
+            h->d_tree_geom = static_cast<float4*>(d_tree_geom.ptr);
+            h->d_tree_word = static_cast<uint32_t*>(d_tree_word.ptr);
+            h->d_tree_capacity = nodes;
+        }
+        h->tree_on_device = true;
+    }
+    if (tree == &built) {
+        h->tree = std::move(built);
+    }
     return RT_OK;
 }
 
@@ -684,8 +753,10 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
 
     const size_t image_pixels = static_cast<size_t>(h->width) * h->height;
     const size_t frame_bytes = image_pixels * sizeof(float4);
-    const bool tree = h->use_tree && !h->tree.empty();
-    const bool quad = tree && h->use_quad && !h->quad.empty() && h->d_quad_geom != nullptr && h->d_slot_spheres != nullptr;
+    // a scene has both hierarchies or none; the depth-first one is walked only where it has been put on the device
+    const bool depth_first = h->use_tree && !h->use_quad && !h->tree.empty() && h->tree_on_device;
+    const bool quad = h->use_tree && !depth_first && !h->quad.empty() && h->d_quad_geom != nullptr && h->d_slot_spheres != nullptr;
+    const bool tree = depth_first || quad;
 
     // Workspace of this call: per-frame sums (launches of several frames) and the unit counter (hierarchy).
     float4* partial = h->partial;
@@ -840,11 +911,11 @@ int render_impl(rt_tracer* h, uint32_t first_frame, uint32_t n_frames, uint32_t 
         args.rng_out = (h->rng_capture && last_group) ? h->rng_state : nullptr;
         args.partial = count > 1 ? partial : nullptr;
         args.stats = h->stats;
-        args.tree_geom = tree ? h->d_tree_geom : nullptr;
-        args.tree_word = tree ? h->d_tree_word : nullptr;
+        args.tree_geom = depth_first ? h->d_tree_geom : nullptr;
+        args.tree_word = depth_first ? h->d_tree_word : nullptr;
         args.unit_counter = tree ? unit_counter : nullptr;
-        args.tree_nodes = tree ? h->tree.node_count() : 0u;
-        args.tree_packed = tree && h->tree.packed() ? rt::kTreeFormatPacked : rt::kTreeFormatGlobal;
+        args.tree_nodes = depth_first ? h->tree.node_count() : 0u;
+        args.tree_packed = depth_first && h->tree.packed() ? rt::kTreeFormatPacked : rt::kTreeFormatGlobal;
         args.quad_roots = args.quad_first_leaf = args.quad_prologue = 0u;
         args.quad_margin = 0.0f;
         args.quad_bound = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1260,6 +1331,13 @@ int rt_set_scene_hierarchy(rt_handle h, int enable)
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
     }
+    if (enable == 2) {
+        // the older tree is built and uploaded when it is first asked for
+        const int rc = ensure_depth_first_tree(h, true);
+        if (rc != RT_OK) {
+            return rc;
+        }
+    }
     h->use_tree = enable != 0;
     h->use_quad = enable != 2;
     return RT_OK;
@@ -1293,6 +1371,10 @@ int rt_get_scene_hierarchy(rt_handle h, float* geom, uint32_t* word, uint32_t ca
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
     }
+    const int rc = ensure_depth_first_tree(h, false);
+    if (rc != RT_OK) {
+        return rc;
+    }
     const uint32_t count = h->tree.node_count();
     if (n_nodes != nullptr) {
         *n_nodes = count;
@@ -1314,6 +1396,10 @@ int rt_get_scene_hierarchy_links(rt_handle h, float* geom, uint32_t* link, uint3
 {
     if (h == nullptr) {
         return RT_ERR_BAD_ARGUMENT;
+    }
+    const int rc = ensure_depth_first_tree(h, false);
+    if (rc != RT_OK) {
+        return rc;
     }
     const uint32_t count = h->tree.node_count();
     if (n_nodes != nullptr) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 baseline on the GPU box: the whole GPU suite, the bench line, and the rocprofv3 passes of the benchmark.
+# Baseline on the GPU box: the whole GPU suite, the bench line, and the rocprofv3 passes of the benchmark.
 # Results: gpurun_out/r3b/ and gpurun_out/prof_r3b/.
 set -e
 O=gpurun_out/r3b

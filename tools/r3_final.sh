@@ -1,5 +1,5 @@
 #!/bin/bash
-# End-of-round check on the GPU box: smoke, the whole GPU suite, the bench line, the one-rank native collective path, C5 line.
+# Whole-tree check on the GPU box: smoke, the whole GPU suite, the bench line, the one-rank native collective path, C5 line.
 set -e
 O=gpurun_out/r3i
 mkdir -p $O

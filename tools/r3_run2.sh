@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 measurements, second batch (GPU box): contract-cost report, unit-size sweep of multi-frame hierarchy launches.
+# Measurements on the GPU box: contract-cost report, unit-size sweep of multi-frame hierarchy launches.
 set -e
 O=gpurun_out/r3a
 mkdir -p $O

@@ -147,11 +147,46 @@ def cpu_baseline(pkg, wl, budget_s=10.0):
 
     rate, frames, dt = run(wl["width"], wl["height"], wl["spp"], wl["depth"], wl["aperture"], 2, budget_s)
     c1_rate, c1_frames, c1_dt = run(1280, 720, 1, 8, 0.05, 8, 1.0)
-    return {"value": rate, "unit": "samples/s", "cores": threads, "host_cpus": machine, "kind": "port",
-            "sample": "frames 0..%d of the same workload (%.3g samples, %.1f s, %d threads of %d host CPUs)" % (
-                frames - 1, wl["width"] * wl["height"] * wl["spp"] * frames, dt, threads, machine),
-            "c1": {"value": c1_rate, "unit": "samples/s",
-                   "sample": "1280x720, 1 spp, depth 8, aperture 0.05, frames 0..%d (%.2f s)" % (c1_frames - 1, c1_dt)}}
+    result = {"value": rate, "unit": "samples/s", "cores": threads, "host_cpus": machine, "kind": "port",
+              "sample": "frames 0..%d of the same workload (%.3g samples, %.1f s, %d threads of %d host CPUs)" % (
+                  frames - 1, wl["width"] * wl["height"] * wl["spp"] * frames, dt, threads, machine),
+              "c1": {"value": c1_rate, "unit": "samples/s",
+                     "sample": "1280x720, 1 spp, depth 8, aperture 0.05, frames 0..%d (%.2f s)" % (c1_frames - 1, c1_dt)}}
+    result["reference_on_lavapipe"] = lavapipe_baseline(pkg, wl, scene, threads, budget_s)
+    if result["reference_on_lavapipe"].get("available"):
+        # the reference's own shader ran on this machine's cores: that is the baseline, the port rides along
+        ref = result["reference_on_lavapipe"]
+        result["port"] = {"value": rate, "unit": "samples/s", "cores": threads, "sample": result["sample"]}
+        result.update(value=ref["value"], kind="reference", cores=threads,
+                      sample="%d frames of the same workload through shaders/raytrace.comp.glsl on %s (%.1f s)" % (
+                          ref["frames"], ref["device"], ref["seconds"]))
+    return result
+
+
+def lavapipe_baseline(pkg, wl, scene, threads, budget_s):
+    """The reference shader itself on Mesa lavapipe (oracle/lavapipe.py, oracle/_ref/lavapipe_harness): runs where the
+    machine has a Vulkan loader, lavapipe and a SPIR-V build of the shader -- RT_LAVAPIPE_SPV names one, or a GLSL
+    compiler on PATH builds it from RT_LAVAPIPE_SHADER (default: the reference tree).  Anywhere else the entry says
+    what is missing; the figure is never estimated."""
+    try:
+        from oracle import lavapipe
+        lavapipe.probe(timeout=20)
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="lavapipe_") as tmp:
+            spv = os.environ.get("RT_LAVAPIPE_SPV") or lavapipe.compile_shader(
+                os.environ.get("RT_LAVAPIPE_SHADER", lavapipe.DEFAULT_SHADER), os.path.join(tmp, "raytrace.comp.spv"))
+            host = pkg.RayTracer().create(wl["width"], wl["height"], device_id=-1)
+            host.set_samples_per_pixel(wl["spp"])
+            host.set_max_depth(wl["depth"])
+            host.set_aperture(wl["aperture"])
+            words = host.get_params_words(0)
+            host.destroy()
+            os.environ.setdefault("LP_NUM_THREADS", str(threads))
+            out = lavapipe.baseline(spv, words, scene, budget_s=budget_s)
+        out["available"] = True
+        return out
+    except Exception as e:  # noqa: BLE001 -- Unavailable says what is missing; anything else must not stop the GPU leg
+        return {"available": False, "reason": "%s: %s" % (type(e).__name__, e)}
 
 
 def other_call_patterns(pkg, device_index, stream):

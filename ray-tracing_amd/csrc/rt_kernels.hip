@@ -53,6 +53,13 @@ namespace {
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 1
 #endif
+// Waves per SIMD asked of the compiler for the walks of the four-way tree in workgroups of up to 512 threads (1 = no
+// constraint: 103 vector registers, four waves).  With 5 the kernels fit 96 registers and a fifth wave, at 8 to 24
+// bytes of spilled registers per lane: within 1 % either way on the 485-sphere scene and on grids of 1024 to 262 144
+// spheres (the walk is bound by instruction issue, not by latency).
+#ifndef RT_QUAD_WAVES_PER_SIMD
+#define RT_QUAD_WAVES_PER_SIMD 1
+#endif
 // Scalar registers per wave.  96 is the most that lets eight waves share a SIMD (the kernel needs
 // fewer than 64 vector registers); left to itself the compiler takes about 104, which caps the
 // SIMD at seven waves and costs 4.6 % on the benchmark.
@@ -343,7 +350,9 @@ struct TreeWalk {
                          // test and have not been visited yet (lowest four bits: the siblings of `grp` itself)
     uint32_t root;       // the level-0 group the walk is below
     f3 inv;              // 1 / d per axis, clamped to +-2^90
-    f3 lo_off, hi_off;   // -(o + m) * inv and -(o - m) * inv, m the margin of this ray's boxes (rt_tree.cpp)
+    f3 near_off, far_off; // per axis -(o + m) * inv and -(o - m) * inv, m the margin of this ray's boxes (rt_tree.cpp):
+                         // the first belongs to the plane the ray crosses first, i.e. they are swapped where inv < 0
+    uint32_t sel_x, sel_y, sel_z; // 48 where inv < 0 on that axis, else 0: byte offset from a group's low bounds to its high ones
 };
 constexpr uint32_t kQuadIdle = 0xFFFFFFFFu;
 
@@ -497,13 +506,17 @@ __device__ __forceinline__ void sphere_closest_slot(const SphereQuadratic& q, co
 // its rounding is harmless are described in rt_tree.cpp.  Returns a key for choosing the child to visit first:
 // the bits of the entry parameter (>= 0, so they order like the floats) with the child's number k in the two lowest
 // bits, or all ones for a child the ray does not reach.
-__device__ __forceinline__ uint32_t box_reached(float lx, float ly, float lz, float hx, float hy, float hz, const TreeWalk& t, uint32_t k)
+// nx .. fz: the child's bounds on the three axes, on each axis the one the ray crosses first and the one it crosses
+// last (the low and the high bound, swapped where the ray runs towards lower coordinates).  The two slab
+// parameters of an axis are ordered by construction -- fma is monotonic in each operand, the low plane's offset
+// is the smaller one exactly when inv >= 0 -- so no minimum or maximum per axis is needed.
+__device__ __forceinline__ uint32_t box_reached(float nx, float ny, float nz, float fx, float fy, float fz, const TreeWalk& t, uint32_t k)
 {
-    const float ax = __builtin_fmaf(lx, t.inv.x, t.lo_off.x), bx = __builtin_fmaf(hx, t.inv.x, t.hi_off.x);
-    const float ay = __builtin_fmaf(ly, t.inv.y, t.lo_off.y), by = __builtin_fmaf(hy, t.inv.y, t.hi_off.y);
-    const float az = __builtin_fmaf(lz, t.inv.z, t.lo_off.z), bz = __builtin_fmaf(hz, t.inv.z, t.hi_off.z);
-    const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
-    const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), t.closest);
+    const float ax = __builtin_fmaf(nx, t.inv.x, t.near_off.x), bx = __builtin_fmaf(fx, t.inv.x, t.far_off.x);
+    const float ay = __builtin_fmaf(ny, t.inv.y, t.near_off.y), by = __builtin_fmaf(fy, t.inv.y, t.far_off.y);
+    const float az = __builtin_fmaf(nz, t.inv.z, t.near_off.z), bz = __builtin_fmaf(fz, t.inv.z, t.far_off.z);
+    const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), 0.0f);
+    const float tf = fminf(fminf(fminf(bx, by), bz), t.closest);
     return tn <= tf ? ((__float_as_uint(tn) & ~3u) | k) : 0xFFFFFFFFu;
 }
 
@@ -544,8 +557,17 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
             t.inv = mk(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.x), -0x1p90f, 0x1p90f),
                        __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.y), -0x1p90f, 0x1p90f),
                        __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(rd.z), -0x1p90f, 0x1p90f));
-            t.lo_off = mk(-(ro.x + margin) * t.inv.x, -(ro.y + margin) * t.inv.y, -(ro.z + margin) * t.inv.z);
-            t.hi_off = mk(-(ro.x - margin) * t.inv.x, -(ro.y - margin) * t.inv.y, -(ro.z - margin) * t.inv.z);
+            const f3 lo_off = mk(-(ro.x + margin) * t.inv.x, -(ro.y + margin) * t.inv.y, -(ro.z + margin) * t.inv.z);
+            const f3 hi_off = mk(-(ro.x - margin) * t.inv.x, -(ro.y - margin) * t.inv.y, -(ro.z - margin) * t.inv.z);
+            // where the ray runs towards lower coordinates it crosses a box's high plane first (the sign bit, so that
+            // a direction component of -0, whose reciprocal is clamped to -2^90, counts as negative like its inv)
+            const bool neg_x = (int32_t)__float_as_uint(t.inv.x) < 0, neg_y = (int32_t)__float_as_uint(t.inv.y) < 0,
+                       neg_z = (int32_t)__float_as_uint(t.inv.z) < 0;
+            t.near_off = mk(neg_x ? hi_off.x : lo_off.x, neg_y ? hi_off.y : lo_off.y, neg_z ? hi_off.z : lo_off.z);
+            t.far_off = mk(neg_x ? lo_off.x : hi_off.x, neg_y ? lo_off.y : hi_off.y, neg_z ? lo_off.z : hi_off.z);
+            t.sel_x = neg_x ? 48u : 0u;
+            t.sel_y = neg_y ? 48u : 0u;
+            t.sel_z = neg_z ? 48u : 0u;
             t.stack = 0u;
             t.root = 0u;
             t.grp = 0u;
@@ -576,12 +598,16 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
         if (t.grp < first_leaf) {
             // (an idle lane's group is 0xFFFFFFFF)
             st.section(ST_NODE);
-            const float4* b = tree + 6u * t.grp;
-            const float4 lx = b[0], ly = b[1], lz = b[2], hx = b[3], hy = b[4], hz = b[5];
-            const uint32_t k0 = box_reached(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t, 0u);
-            const uint32_t k1 = box_reached(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t, 1u);
-            const uint32_t k2 = box_reached(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t, 2u);
-            const uint32_t k3 = box_reached(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t, 3u);
+            // a group: the low bounds of its four children on x, y, z (three float4), then the high bounds; per axis the
+            // bound the ray crosses first is read at a per-lane offset of 0 or 48 bytes, the other one at the opposite
+            const char* b = reinterpret_cast<const char*>(tree) + 96u * t.grp;
+            const float4 nx = *reinterpret_cast<const float4*>(b + t.sel_x), fx = *reinterpret_cast<const float4*>(b + 48u - t.sel_x);
+            const float4 ny = *reinterpret_cast<const float4*>(b + 16u + t.sel_y), fy = *reinterpret_cast<const float4*>(b + 64u - t.sel_y);
+            const float4 nz = *reinterpret_cast<const float4*>(b + 32u + t.sel_z), fz = *reinterpret_cast<const float4*>(b + 80u - t.sel_z);
+            const uint32_t k0 = box_reached(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, t, 0u);
+            const uint32_t k1 = box_reached(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, t, 1u);
+            const uint32_t k2 = box_reached(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, t, 2u);
+            const uint32_t k3 = box_reached(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, t, 3u);
             const uint32_t pass = (k0 != 0xFFFFFFFFu ? 1u : 0u) | (k1 != 0xFFFFFFFFu ? 2u : 0u) | (k2 != 0xFFFFFFFFu ? 4u : 0u) |
                                   (k3 != 0xFFFFFFFFu ? 8u : 0u);
             if (pass != 0u) {
@@ -733,7 +759,7 @@ __device__ __forceinline__ uint32_t load_unit(const TraceArgs& A_in_registers, u
 // kByCounter: the hierarchy kernels, see below.
 // STRIPES: the launch renders interleaved stripes of rows (TraceArgs::stripe_rows != 0) instead of one band.
 template <int MODE, class Stats, int BLOCK, int PERSISTENT, bool STRIPES>
-__global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
+__global__ __launch_bounds__(BLOCK, (MODE == kTreeQuadGlobal || (MODE == kTreeQuad && BLOCK <= 512)) ? RT_QUAD_WAVES_PER_SIMD : RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trace_kernel(TraceArgs A)
 {
     constexpr bool MAT_IN_LDS = MODE == kFullLds || MODE == kFullLds5;
     extern __shared__ float4 lds[];
@@ -880,7 +906,8 @@ __global__ __launch_bounds__(BLOCK, RT_WAVES_PER_SIMD) RT_SGPR_ATTR void rt_trac
     walk.grp = kQuadIdle;
     walk.stack = 0u;
     walk.root = 0u;
-    walk.inv = walk.lo_off = walk.hi_off = mk(0.0f, 0.0f, 0.0f);
+    walk.inv = walk.near_off = walk.far_off = mk(0.0f, 0.0f, 0.0f);
+    walk.sel_x = walk.sel_y = walk.sel_z = 0u;
 
     for (;;) {
         st.section(ST_ITER);

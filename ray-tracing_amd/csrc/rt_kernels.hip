@@ -81,9 +81,11 @@ constexpr uint32_t kRegenQuorum = RT_REGEN_QUORUM;
 constexpr uint32_t kWalkQuorum = RT_WALK_QUORUM;
 // The same for the walk of the four-way tree, whose trips are cheap next to the shading blocks that follow a round.
 // Measured on the 4096-sphere scene (1920 x 1080, depth 50, 8 frames): 12: 48.5 ms, 16: 45.5, 24: 41.9, 32: 40.9,
-// 40: 40.7, 48: 41.5, 56: 44.6 (with a fixed quorum of 32 lanes for the groups of spheres).
+// 40: 40.7, 48: 41.5, 56: 44.6 (with a fixed quorum of 32 lanes for the groups of spheres).  Again once a box trip
+// had lost a quarter of its instructions (no per-axis minimum and maximum), 8 frames: 32: 34.1 ms, 40: 32.0, 44: 31.5,
+// 48: 31.2, 52: 31.2, 56: 31.6, 60: 32.6.
 #ifndef RT_QUAD_WALK_QUORUM
-#define RT_QUAD_WALK_QUORUM 40
+#define RT_QUAD_WALK_QUORUM 48
 #endif
 constexpr uint32_t kQuadWalkQuorum = RT_QUAD_WALK_QUORUM;
 // Four-way tree: the groups of spheres of the last level are tested when this share (in eighths) of the lanes that

@@ -446,7 +446,12 @@ def _box_interval(lo, hi, inv, lo_off, hi_off):
     """[tn, tf] of the kernel's slab test before the clamps to 0 and `closest`; lo/hi (..., 3)."""
     a = _fma(lo, inv, lo_off)
     b = _fma(hi, inv, hi_off)
-    return np.minimum(a, b).max(axis=-1), np.maximum(a, b).min(axis=-1)
+    # The kernel takes no minimum or maximum per axis: it reads the bound the ray crosses first (the high one where the
+    # sign bit of inv is set) and the one it crosses last, and the two parameters are ordered by construction.
+    neg = np.signbit(np.broadcast_to(inv, a.shape))
+    near, far = np.where(neg, b, a), np.where(neg, a, b)
+    assert np.all(near <= far), "a slab's two parameters came out in the wrong order"
+    return near.max(axis=-1), far.min(axis=-1)
 
 
 def _quad_walk_closest(q, scene, o, d):

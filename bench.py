@@ -49,7 +49,7 @@ WORKLOADS = {
                flops_key="c4_8k_spp256_depth8_dof_on",
                text="default 5-sphere scene, 7680x4320, 256 spp, depth 8, DoF on, one frame"),
     # 32 frames per step (the configuration fixes no frame count): with 8 ranks that is four frames per rank and launch,
-    # which amortises the ramp and drain of a hierarchy launch (one frame per rank projects to 6.0x, four to 7.1x)
+    # which amortises the ramp and drain of a hierarchy launch (one frame per rank projects to 6.1x, four to 7.1x)
     "c5": dict(width=1920, height=1080, spp=16, depth=50, aperture=0.05, frames=32, scene="synthetic4096",
                flops_key="c5_4096_spheres_depth50",
                text="synthetic 4096-sphere mixed-material scene, 1920x1080, 16 spp/frame, depth 50, 32 frames"),
@@ -571,7 +571,7 @@ def main():
                         "x 96 B per box group / 64 B per group of spheres x samples per launch / HIP-event kernel time; peak = "
                         "256 CU x 128 B/clk x 2.4 GHz of LDS bandwidth.  The fraction is low because the walk is bound by VALU "
                         "issue at the 4 waves per SIMD its LDS footprint allows (one 1024-thread workgroup per CU holds the "
-                        "tree; profiles/r3c_c5/pmc_summary.json: 3.3 SIMD-cycles per VALU instruction at 32 of 64 lanes), "
+                        "tree; the PMC figures of the latest committed profile of this workload are in `valu`), "
                         "not by LDS bytes; HBM traffic is negligible"}
         elif flops_per_sample is not None:
             achieved = flops_per_sample * launch_samples / avg_kernel_s / 1e12

@@ -22,16 +22,19 @@ def _word_sum(array):
     return int((words * weights).sum(dtype=np.uint64))
 
 
-def test_cpp_caller_renders_what_the_python_mirror_renders(pkg, oracle):
-    exe = os.path.join(ROOT, "tests", "_bin", "cpp_frame_loop")
-    assert os.path.isfile(exe), "tests/_bin/cpp_frame_loop is missing: run make -C tests (or __graft_entry__.build())"
+def _stages_of(exe):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert run.returncode == 0, run.stdout + run.stderr
     got = {}
     for line in run.stdout.strip().splitlines():
         stage, accum_sum, output_sum = line.split()
         got[stage] = (int(accum_sum, 16), int(output_sum, 16))
+    return got
 
+
+@pytest.fixture(scope="module")
+def python_mirror_stages(pkg, oracle):
+    """The calls of the C++ programs replayed through the Python mirror, every stage checked against the oracle."""
     scene = pkg.default_scene()
     t = pkg.RayTracer().create(320, 180, device_id=0)      # create-time defaults, as the C++ program has them
     t.set_samples_per_pixel(4)
@@ -62,4 +65,20 @@ def test_cpp_caller_renders_what_the_python_mirror_renders(pkg, oracle):
     t.render_frames(1, 4)
     stage("resized", range(5))
     t.destroy()
-    assert got == want
+    return want
+
+
+def test_cpp_caller_renders_what_the_python_mirror_renders(python_mirror_stages):
+    exe = os.path.join(ROOT, "tests", "_bin", "cpp_frame_loop")
+    assert os.path.isfile(exe), "tests/_bin/cpp_frame_loop is missing: run make -C tests (or __graft_entry__.build())"
+    assert _stages_of(exe) == python_mirror_stages
+
+
+def test_the_reference_class_bound_to_the_library_renders_the_same(python_mirror_stages):
+    """tests/ref_class_frame_loop.cpp: the reference's own class RayTracer (its header, used where it lies) with
+    ray-tracing_amd/csrc/RayTracer_mi355x.cpp in the place of the reference's RayTracer.cpp, driven like App::run.
+    The program is built where the reference tree is mounted (make -C oracle ref) and travels as a binary."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_class_frame_loop")
+    if not os.path.isfile(exe):
+        pytest.skip("oracle/_ref/ref_class_frame_loop is built where the reference's headers are")
+    assert _stages_of(exe) == python_mirror_stages

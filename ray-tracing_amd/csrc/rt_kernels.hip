@@ -641,18 +641,27 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
             const SphereQuadratic q1 = sphere_quadratic(b1, ro, rd, t.rden.a);
             const SphereQuadratic q2 = sphere_quadratic(b2, ro, rd, t.rden.a);
             const SphereQuadratic q3 = sphere_quadratic(b3, ro, rd, t.rden.a);
-            const bool s0 = q0.discriminant < 0.0f || behind_origin(q0.half_b, q0.c);
-            const bool s1 = q1.discriminant < 0.0f || behind_origin(q1.half_b, q1.c);
-            const bool s2 = q2.discriminant < 0.0f || behind_origin(q2.half_b, q2.c);
-            const bool s3 = q3.discriminant < 0.0f || behind_origin(q3.half_b, q3.c);
-            const uint32_t pass = (s0 ? 0u : 1u) | (s1 ? 0u : 2u) | (s2 ? 0u : 4u) | (s3 ? 0u : 8u);
+            // A sphere goes on to the root arithmetic unless its discriminant is negative or it lies behind the origin
+            // (behind_origin: half_b and c both with a clear sign bit).  All of it is sign bits here: rays that walk the
+            // tree are in the bounded range, so no discriminant is a NaN, and none is -0 either (half_b * half_b is never
+            // -0, and x - y is -0 only for x = -0) -- `discriminant < 0` is the sign bit of the discriminant.
+            const uint32_t t0 = (__float_as_uint(q0.half_b) | __float_as_uint(q0.c)) & ~__float_as_uint(q0.discriminant);
+            const uint32_t t1 = (__float_as_uint(q1.half_b) | __float_as_uint(q1.c)) & ~__float_as_uint(q1.discriminant);
+            const uint32_t t2 = (__float_as_uint(q2.half_b) | __float_as_uint(q2.c)) & ~__float_as_uint(q2.discriminant);
+            const uint32_t t3 = (__float_as_uint(q3.half_b) | __float_as_uint(q3.c)) & ~__float_as_uint(q3.discriminant);
+            const uint32_t pass = (t0 >> 31) | ((t1 >> 30) & 2u) | ((t2 >> 29) & 4u) | ((t3 >> 28) & 8u);
             const int slot0 = (int)(4u * (t.grp - first_leaf));
             for (uint32_t m = pass; m != 0u; m &= m - 1u) {
                 const uint32_t i = (uint32_t)__builtin_ctz(m);
-                SphereQuadratic q = q0;
-                if (i == 1u) { q = q1; }
-                if (i == 2u) { q = q2; }
-                if (i == 3u) { q = q3; }
+                // the two values the root arithmetic needs, picked by two levels of selects: as branches (which is what
+                // an assignment of the whole record under `if` compiles to) the choice cost 2 % of the 4096-sphere launch
+                const bool odd = (i & 1u) != 0u, upper = i >= 2u;
+                const float hb_lo = odd ? q1.half_b : q0.half_b, hb_hi = odd ? q3.half_b : q2.half_b;
+                const float d_lo = odd ? q1.discriminant : q0.discriminant, d_hi = odd ? q3.discriminant : q2.discriminant;
+                SphereQuadratic q;
+                q.half_b = upper ? hb_hi : hb_lo;
+                q.discriminant = upper ? d_hi : d_lo;
+                q.c = 0.0f; // not used from here on
                 sphere_closest_slot(q, t.rden, kTMin, slot0 + (int)i, A.spheres, t.closest, t.best, st);
             }
             done_here = true;

@@ -479,28 +479,22 @@ __device__ __forceinline__ void sphere_closest_slot(const SphereQuadratic& q, co
     st.section(ST_ROOT);
     const float sqrt_disc = sqrt_exact(q.discriminant);
     float root = root_div(-q.half_b - sqrt_disc, rden);
-    if (root > closest) {
-        // The far root is no smaller than the near one (the square root is >= 0 and a correctly rounded division by
-        // a > 0 is monotonic), so :127-129 would reject it as well: a sphere behind the closest hit costs one root.
-        return;
-    }
-    if (root < tmin) {
+    // The far root is no smaller than the near one (the square root is >= 0 and a correctly rounded division by
+    // a > 0 is monotonic), so :127-129 would reject it as well: a sphere behind the closest hit costs one root.
+    bool accepted = !(root > closest);
+    if (accepted && root < tmin) {
         st.section(ST_FAR_ROOT);
         root = root_div(-q.half_b + sqrt_disc, rden);
-        if (root < tmin || root > closest) {
-            return;
-        }
+        accepted = !(root < tmin || root > closest);
     }
-    bool take = root < closest;
-    if (!take) {
+    bool take = accepted && root < closest;
+    if (accepted && !take) {
         RT_COLD_PATH();
         take = best < 0 || slot_sphere_index(slot_spheres, slot) > slot_sphere_index(slot_spheres, best);
     }
-    if (take) {
-        RT_KEEP_BRANCH();
-        closest = root;
-        best = slot;
-    }
+    // (selects: as branches, the early return and the assignment cost more than the few instructions they skip)
+    closest = take ? root : closest;
+    best = take ? slot : best;
 }
 
 // One child of a box group against the ray: whether the parameter interval inside the box, grown by the ray's
@@ -592,7 +586,8 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
     // the round ends when fewer than this many lanes are still walking
     const uint32_t in_loop = (uint32_t)__popcll(wave_ballot(true));
     const uint32_t few = __builtin_amdgcn_readfirstlane(kQuadWalkQuorum != 0u && in_loop > kQuadWalkQuorum ? in_loop - kQuadWalkQuorum : 0u);
-    if ((uint32_t)__popcll(wave_ballot(t.grp != kQuadIdle)) <= few) {
+    unsigned long long walking = wave_ballot(t.grp != kQuadIdle);
+    if ((uint32_t)__popcll(walking) <= few) {
         return;
     }
     do {
@@ -623,15 +618,18 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
                 done_here = true;
             }
         }
-        const bool at_spheres = !done_here && t.grp != kQuadIdle && t.grp >= first_leaf;
+        // (a lane whose box group failed keeps that group, which lies above the last level; an idle lane's is all ones)
+        const bool at_spheres = t.grp - first_leaf < kQuadIdle - first_leaf;
         bool spheres_now = true;
         if (kLeafShare != 0u) {
-            // The groups of spheres are tested when enough lanes stand at one, or when no lane has a box group to go on
-            // with; until then those lanes keep their place.  (The block costs the wave the same however few lanes
-            // need it, and a trip that tests both kinds of group costs more than twice the box block alone.)
+            // The groups of spheres are tested when enough of the walking lanes stand at one; until then those lanes
+            // keep their place.  (The block costs the wave the same however few lanes need it, and a trip that tests
+            // both kinds of group costs more than twice the box block alone.)  When no lane has a box group to go on
+            // with, every walking lane stands at a group of spheres and the quorum, a share of them, is met.
+            static_assert(kLeafShare <= 8u, "the quorum must not exceed the walking lanes");
             const uint32_t waiting = (uint32_t)__popcll(wave_ballot(at_spheres));
-            const uint32_t quorum = ((uint32_t)__popcll(wave_ballot(t.grp != kQuadIdle)) * kLeafShare) >> 3;
-            spheres_now = waiting >= quorum || wave_ballot(t.grp < first_leaf) == 0ull;
+            const uint32_t quorum = ((uint32_t)__popcll(walking) * kLeafShare) >> 3; // (the box block leaves no lane idle)
+            spheres_now = waiting >= quorum;
         }
         if (at_spheres && spheres_now) {
             st.section(ST_SPHERE_TEST);
@@ -684,7 +682,8 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
                 t.grp = ((at - roots) & ~3u) + roots + i;
             }
         }
-    } while ((uint32_t)__popcll(wave_ballot(t.grp != kQuadIdle)) > few);
+        walking = wave_ballot(t.grp != kQuadIdle);
+    } while ((uint32_t)__popcll(walking) > few);
 }
 
 // A unit of work: a pixel tile x a chunk of frames, pooled by one wave.  Its description lives in

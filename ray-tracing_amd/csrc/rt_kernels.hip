@@ -670,16 +670,17 @@ __device__ __forceinline__ void quad_walk(const TraceArgs& A, const float4* tree
                 t.root += 1u;
                 t.grp = t.root < roots ? t.root : kQuadIdle;
             } else {
-                // up to the nearest level where a sibling waits, and across to it
-                uint32_t up = (uint32_t)__builtin_ctz(t.stack) >> 2;
-                t.stack >>= 4u * up;
-                uint32_t at = t.grp;
-                for (; up != 0u; --up) {
-                    at = (at - roots) >> 2;
-                }
-                const uint32_t i = (uint32_t)__builtin_ctz(t.stack);
+                // Up to the nearest level where a sibling waits, and across to it.  The parent of group g is
+                // (g - roots) >> 2, so its ancestor `up` levels higher is (g - roots * (4^up - 1) / 3) >> (2 up) -- the
+                // subtrahends of the single steps add up, each shifted by the steps that follow it, and the floors
+                // compose -- with (4^up - 1) / 3 = the `up` lowest bits of 0x55555555...: no loop over the levels.
+                const uint32_t c = (uint32_t)__builtin_ctz(t.stack);
+                const uint32_t up4 = c & ~3u;                                     // 4 * up
+                const uint32_t up2 = up4 >> 1;                                    // 2 * up
+                const uint32_t at = (t.grp - roots * (0x55555555u & ((1u << up2) - 1u))) >> up2;
+                t.stack >>= up4;
                 t.stack &= t.stack - 1u;
-                t.grp = ((at - roots) & ~3u) + roots + i;
+                t.grp = ((at - roots) & ~3u) + roots + (c & 3u);
             }
         }
         walking = wave_ballot(t.grp != kQuadIdle);

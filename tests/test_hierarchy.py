@@ -857,3 +857,26 @@ def test_largest_four_way_tree_kept_in_lds(pkg):
         b = _render(pkg, scene, False, w=64, h=40, spp=1, depth=4, frames=2)
         for x, y in zip(a, b):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+def test_ancestor_of_a_group_in_closed_form():
+    """The walk goes up `up` levels at once: the parent of group g is (g - roots) >> 2, and the kernel takes the
+    ancestor `up` levels higher as (g - roots * (4^up - 1) / 3) >> (2 up), with (4^up - 1) / 3 read off 0x55555555.
+    Checked against the step-by-step parent for every group of trees of every shape the builder makes."""
+    for roots in range(1, 17):
+        for levels in range(1, 7):
+            first = [0]
+            for level in range(levels):
+                first.append(first[-1] + roots * 4 ** level)          # first group of each level, and the group count
+            groups = np.arange(first[-1], dtype=np.int64)
+            level_of = np.searchsorted(np.asarray(first[1:]), groups, side="right")
+            for up in range(0, levels):
+                sel = groups[level_of >= up]
+                step = sel.copy()
+                for _ in range(up):
+                    step = (step - roots) >> 2
+                e = 0x55555555 & ((1 << (2 * up)) - 1)
+                assert e == (4 ** up - 1) // 3
+                closed = (sel - roots * e) >> (2 * up)
+                assert np.array_equal(step, closed)
+                assert np.array_equal(np.searchsorted(np.asarray(first[1:]), closed, side="right"), level_of[level_of >= up] - up)

@@ -94,6 +94,20 @@ def load_measured_traffic():
     return best, source, derived
 
 
+def load_uniform_lanes_probe():
+    """What the same kernel reached on views whose lanes all do the same thing (tools/uniform_lanes_probe.py): the
+    most recent committed profiles/r*/uniform_lanes_probe.json, as {view: algorithmic TFLOP/s}, and the file's path."""
+    import re
+    found, source = {}, None
+    base = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(base)):
+        path = os.path.join(base, name, "uniform_lanes_probe.json")
+        if re.fullmatch(r"r\d+[a-z]*", name) and os.path.isfile(path):
+            found = {view: rec["tflops"] for view, rec in json.load(open(path)).items()}
+            source = os.path.relpath(path, ROOT)
+    return found, source
+
+
 def load_workload_pmc(workload):
     """Per-launch figures of the committed rocprofv3 PMC passes of another workload (profiles/r<round><letter>_<workload>/),
     the most recent one, with the file they were read from; ({}, None) if there is none."""
@@ -584,6 +598,7 @@ def main():
                 "valu_insts_per_wave_sample": pmc.get("valu_insts_per_wave_sample"),
                 "simd_cycles_per_valu_inst": pmc.get("simd_cycles_per_valu_inst"),
                 "kernel_ms": avg_kernel_s * 1e3, "flops_per_sample": flops_per_sample,
+                "same_kernel_with_uniform_lanes": dict(zip(("tflops_by_view", "source"), load_uniform_lanes_probe())),
                 "ceilings": {"unit": "TFLOP/s", "fma_every_slot": PEAK_FP32_VALU_TFLOPS,
                              "one_flop_per_slot": PEAK_FP32_VALU_TFLOPS / 2,
                              "one_flop_per_slot_at_measured_issue_rate": PEAK_FP32_VALU_TFLOPS / 2 * 2.0 / 2.45,

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Whole-tree check on the GPU box: smoke, the whole GPU suite, the bench line, the one-rank native collective path, C5 line,
-# and the rocprofv3 passes of the benchmark command.   Usage: bash tools/r3_final.sh <tag>
+# and the rocprofv3 passes of the benchmark command.   Usage: bash tools/gpu_check.sh <tag>
 set -e
-O=gpurun_out/${1:-r3m}
+O=gpurun_out/${1:-check}
 mkdir -p $O
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }
@@ -17,7 +17,7 @@ for m in tiles frames; do
 done
 timeout -k 10 200 python bench.py --workload c5 --mode frames --force-distributed --steps 4 --warmup 1 --no-cpu-baseline --verify > $O/force_distributed_c5_native.json 2> $O/err.log || { tail -20 $O/err.log; exit 1; }
 python -c "import json; d=json.load(open('$O/force_distributed_c5_native.json')); print('c5 frames', d['value'], d.get('verified_against_one_gpu'))"
-bash tools/profile_bench.sh ${1:-r3m}
-python tools/summarize_profile.py ${1:-r3m} > $O/summary.log 2>&1 || tail -5 $O/summary.log
-mkdir -p $O/profiles && cp profiles/${1:-r3m}/* $O/profiles/
+bash tools/profile_bench.sh ${1:-check}
+python tools/summarize_profile.py ${1:-check} > $O/summary.log 2>&1 || tail -5 $O/summary.log
+mkdir -p $O/profiles && cp profiles/${1:-check}/* $O/profiles/
 tail -14 $O/summary.log

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Figures of the hierarchy kernels after a change of the box walk (GPU box): C5 at 1 / 8 / 32 / 64 frames per launch, rank 0's
 # part of an eight-rank frame split, C5m and the random scene, the synthetic grid from 4096 to a million spheres, the section
-# counters of the diagnostic build and the rocprofv3 passes of the 8-frame launch.   Usage: bash tools/r3_refresh.sh <tag>
+# counters of the diagnostic build and the rocprofv3 passes of the 8-frame launch.   Usage: bash tools/hierarchy_refresh.sh <tag>
 set -e
-TAG=${1:-r3k}
+TAG=${1:-hierarchy}
 O=gpurun_out/$TAG
 mkdir -p $O
 p() { python -c "import json,sys; d=json.load(open('$1')); print('$2', 'ms_per_step %.3f value %.4e kernel_ms %.3f' % (d['ms_per_step'], d['value'], d['roofline']['kernel_ms']))"; }

@@ -56,7 +56,9 @@ int main()
         Swapchain swapchain;
         swapchain.mSwapchainBundle.extent = { 320, 180 };
         RayTracer tracer;
+        rt_mi355x_set_device(0);
         tracer.create(context, swapchain);
+        rt_mi355x_set_stream(&tracer, nullptr); // the null stream, which is also the default
         tracer.setSamplesPerPixel(4);
         tracer.setAperture(0.05f);
         uint32_t frame = 0;

@@ -283,7 +283,9 @@ def main():
     ap.add_argument("--comm-priority", type=int, default=0, help="priority of the stream the collective runs on")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed steps rank 0 renders all their frames again on its own GPU and compares the image "
-                         "the ranks put together with it (tiles: bit for bit; frames: relative RMSE)")
+                         "the ranks put together with it (tiles: bit for bit; frames: relative RMSE); on by itself whenever "
+                         "more than one rank runs (a few seconds, outside the timed region)")
+    ap.add_argument("--no-verify", action="store_true", help="skip that comparison in a run of several ranks")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -498,7 +500,7 @@ def main():
     value = samples_per_step * args.steps / elapsed
 
     verified = None
-    if args.verify and distributed and rank == 0 and not rehearse:
+    if (args.verify or world > 1) and not args.no_verify and distributed and rank == 0 and not rehearse:
         import numpy as np
         last = (args.warmup + args.steps - 1) % 2
         if native is not None:
